@@ -1,0 +1,179 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+ctypes front-end for the two checker libraries:
+
+  * ``libsea_oracle.so``       the CPU restatement (oracle/ns_oracle.c, oracle/resynth_oracle.c)
+  * ``_ref/libetsi_ref.so``    the reference's own C (etsi/cpp/*.c) compiled where it lies under
+                               /root/reference, plus oracle/ref_driver*.c (only where it was built)
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg may import this
+module.  The product package ``speech_enhancement_amd`` never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(_HERE, "libsea_oracle.so")
+REF_SO = os.path.join(_HERE, "_ref", "libetsi_ref.so")
+NSCAL = 16
+
+_c_void = ctypes.c_void_p
+
+
+def build(ref=True):
+    """Compile the restatement (always) and the reference build (when /root/reference exists)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"] + (["ref"] if ref else []))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_c_void) if a is not None else None
+
+
+class _Lib:
+    """Common wrapper: the restatement and the reference driver export the same entry points
+    under the prefixes ``ora_`` and ``ref_``."""
+
+    def __init__(self, path, prefix):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = ctypes.CDLL(path)
+        self.p = prefix
+
+    def _f(self, name):
+        return getattr(self.lib, self.p + name)
+
+    def etsi_denoise(self, x, fill=0):
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        out = np.full(x.shape, fill, dtype=np.int16)
+        self._f("etsi_denoise")(_ptr(x), _ptr(out), ctypes.c_long(x.size))
+        return out
+
+    def rfft(self, x):
+        y = np.array(x, dtype=np.float32, copy=True)
+        n = y.size
+        m = int(np.log2(n))
+        assert 1 << m == n
+        self._f("rfft")(_ptr(y), ctypes.c_int(n), ctypes.c_int(m))
+        return y
+
+    def ns_trace(self, x, want_state=True):
+        """Returns dict(out_i16, den_f32[nout*80], ceps[nceps,14], scal[nfr,16], spec[nfr,4,65])."""
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        nfr = x.size // 80
+        out = np.zeros(x.size, np.int16)
+        den = np.zeros(max(nfr, 1) * 80, np.float32)
+        ceps = np.zeros((max(nfr, 1), 14), np.float32)
+        scal = np.zeros((max(nfr, 1), NSCAL), np.float32) if want_state else None
+        spec = np.zeros((max(nfr, 1), 4, 65), np.float32) if want_state else None
+        counts = np.zeros(2, np.int64)
+        self._f("ns_trace")(_ptr(x), ctypes.c_long(x.size), _ptr(out), _ptr(den), _ptr(ceps),
+                            _ptr(scal), _ptr(spec), _ptr(counts))
+        nout, nceps = int(counts[0]), int(counts[1])
+        return dict(out_i16=out, den_f32=den[: nout * 80], ceps=ceps[:nceps],
+                    scal=None if scal is None else scal[:nfr],
+                    spec=None if spec is None else spec[:nfr], nout=nout, nceps=nceps)
+
+    def compceps_frame(self, data201):
+        d = np.ascontiguousarray(data201, dtype=np.float32)
+        assert d.size == 201
+        c = np.zeros(14, np.float32)
+        self._f("compceps_frame")(_ptr(d), _ptr(c))
+        return c
+
+    def ns_tables(self):
+        t = dict(sigWindow=np.zeros(200, np.float32), irWindow=np.zeros(17, np.float32),
+                 idct=np.zeros((25, 25), np.float32), melStart=np.zeros(25, np.int32),
+                 melLen=np.zeros(25, np.int32), melData=np.zeros((25, 16), np.float32))
+        self._f("ns_tables")(*[_ptr(t[k]) for k in
+                               ("sigWindow", "irWindow", "idct", "melStart", "melLen", "melData")])
+        return t
+
+    def cc_tables(self):
+        t = dict(hamming=np.zeros(100, np.float32), dct=np.zeros((12, 23), np.float32),
+                 melStart=np.zeros(23, np.int32), melLen=np.zeros(23, np.int32),
+                 melData=np.zeros((23, 32), np.float32))
+        self._f("cc_tables")(*[_ptr(t[k]) for k in ("hamming", "dct", "melStart", "melLen", "melData")])
+        return t
+
+
+class Oracle(_Lib):
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build(ref=False)
+        super().__init__(ORACLE_SO, "ora_")
+        self.lib.ora_resynth64.restype = ctypes.c_int
+
+    def resynth64(self, x, mask, binary=False):
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        mask = np.ascontiguousarray(mask, dtype=np.float32)
+        out = np.zeros(x.size, np.int16)
+        rc = self.lib.ora_resynth64(_ptr(x), ctypes.c_long(x.size), _ptr(mask),
+                                    ctypes.c_int(mask.shape[0]), ctypes.c_int(int(binary)), _ptr(out))
+        if rc:
+            raise ValueError("ora_resynth64: bad L/F")
+        return out
+
+    def gammatone(self, x, cf, bw, mid_ear):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.zeros_like(x)
+        self.lib.ora_gammatone(_ptr(x), _ptr(y), ctypes.c_float(cf), ctypes.c_float(bw),
+                               ctypes.c_float(mid_ear), ctypes.c_long(x.size))
+        return y
+
+    def resynth_channels(self):
+        cf, bw, me = (np.zeros(64, np.float32) for _ in range(3))
+        self.lib.ora_resynth_channels(_ptr(cf), _ptr(bw), _ptr(me))
+        return cf, bw, me
+
+
+class Reference(_Lib):
+    """The reference C itself (present only where oracle/_ref was built)."""
+
+    def __init__(self):
+        super().__init__(REF_SO, "ref_")
+
+
+def have_reference():
+    return os.path.exists(REF_SO)
+
+
+# ---------------------------------------------------------------------------------------------
+# Seeded signals of SURVEY.md 8(c) (the known-answer inputs)
+# ---------------------------------------------------------------------------------------------
+def _lcg_stream(seed, n):
+    """s <- s*1664525 + 1013904223 (uint32), n successive values AFTER each update."""
+    out = np.empty(n, np.uint32)
+    s = seed & 0xFFFFFFFF
+    for i in range(n):
+        s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+        out[i] = s
+    return out
+
+
+def kat_ns_signal(L=160000, seed=12345):
+    """x[i] = (short)(4000 sin(2 pi 440 i/8000) [(i mod 8000) < 4000] + ((int)(s>>16) % 2001 - 1000))"""
+    s = _lcg_stream(seed, L)
+    i = np.arange(L)
+    tone = 4000.0 * np.sin(2 * np.pi * 440 * i / 8000.0) * ((i % 8000) < 4000)
+    v = tone + ((s >> 16).astype(np.int64) % 2001 - 1000)
+    return np.trunc(v).astype(np.int16)
+
+
+def kat_resynth_case(L=48000, seed=1):
+    """in[i] = (short)(3000 sin(2 pi 500 i/16000) + ((s>>16) % 1001 - 500)); then the SAME LCG
+    continues: m[f][c] = ((s>>16) % 1000)/1000.0f, F = (L-320)/160+1 rows of 64."""
+    F = (L - 320) // 160 + 1
+    s = _lcg_stream(seed, L + F * 64)
+    i = np.arange(L)
+    v = 3000.0 * np.sin(2 * np.pi * 500 * i / 16000.0) + ((s[:L] >> 16).astype(np.int64) % 1001 - 500)
+    x = np.trunc(v).astype(np.int16)
+    m = (((s[L:] >> 16) % 1000).astype(np.float32) / np.float32(1000.0)).reshape(F, 64)
+    return x, m
+
+
+def weighted_checksum(out):
+    out = np.asarray(out).astype(np.int64)
+    return int(np.sum(out * ((np.arange(out.size) % 97) + 1)))
