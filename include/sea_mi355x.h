@@ -1,0 +1,129 @@
+/*
+ * sea_mi355x.h -- C ABI of libsea_mi355x.so, the MI355X (gfx950) engine for the per-frame
+ * noise-suppression hot path of guokiddo1/speech_enhancement.
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Three groups of entry points:
+ *
+ *  (1) DROP-INS with the reference's own names and signatures, so the reference's callers link
+ *      against this library unchanged (host buffers in, host buffers out; the library does the
+ *      H2D/D2H itself):
+ *          etsi_denoise*            etsi/cpp/AdvFrontEnd.h:13-17  (AdvFrontEnd.c:125-329)
+ *          rfft                     etsi/cpp/rfft.h:19            (rfft.c:45-180)
+ *  (2) HANDLE-BASED equivalents of the FEParamsX plug-in slots (etsi/cpp/ParmInterface.h:120-178;
+ *      wired in etsi/cpp/ParmInterface.c:58-82).  INTEGRATION.md shows the 4-line shims that
+ *      install them into the reference's vtable:
+ *          sea_ns_stream_*          DoNoiseSupAlloc/Init/DoNoiseSup/Delete  (NoiseSup.c:859-1440)
+ *          sea_compceps_frame       DoCompCeps                              (CompCeps.c:309-318)
+ *          sea_gammatone_filter     gammaToneFilter   resyth_64sub_ori/cpp/HuWang.h:49
+ *          sea_resynth64            resynth()         resyth_64sub_ori/cpp/extractwav.h:4
+ *                                                     (C form: the reference's takes asdk::CWave)
+ *  (3) BATCH entry points on DEVICE pointers (HBM-resident data, caller's HIP stream): what the
+ *      reference's only parallel harness -- a thread pool over files,
+ *      function/20141106_speech_enhancement/aurora_speech_enhancement/aurora_speech_enhancement.cpp:82-230
+ *      -- becomes on a GPU: one launch over a packed batch of utterances.
+ *
+ * Return convention follows the reference (AdvFrontEnd.c:205-209): 0 (FALSE) = success, non-zero
+ * = fault; sea_last_error() describes the most recent fault on the calling thread.
+ * There is NO CPU fallback: without a usable gfx950 device every call fails.
+ */
+#ifndef SEA_MI355X_H
+#define SEA_MI355X_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ----------------------------------------------------------------------------------------------
+ * (1) drop-ins
+ * -------------------------------------------------------------------------------------------- */
+/* etsi/cpp/AdvFrontEnd.h:13 -- 8 kHz-mode two-stage Wiener denoiser on i_frame samples.
+ * p_denoised[0 .. 80*(i_frame/80)) is written (first 320 samples after the first non-zero frame
+ * are 0: SURVEY F7/F8); the trailing i_frame%80 samples are left untouched, as in the reference. */
+int etsi_denoise(short *p_data, short *p_denoised, long i_frame);
+/* etsi/cpp/AdvFrontEnd.h:14 -- reference behaviour kept: runs etsi_denoise into a scratch buffer
+ * and copies only on fault, i.e. never writes p_denoised on success. */
+int etsi_denoise_synchronization(short *p_data, short *p_denoised, long i_frame);
+/* etsi/cpp/AdvFrontEnd.h:16-17 -- the reference's 16 kHz-mode entry points read 80 shorts past a
+ * heap buffer per frame and nothing calls them; exported so callers link, they
+ * return 1 (fault) without touching p_denoised. */
+int etsi_denoise_16k(short *p_data, short *p_denoised, long i_frame);
+int etsi_denoise_16k_synchronization(short *p_data, short *p_denoised, long i_frame);
+/* etsi/cpp/rfft.h:19 -- in-place real split-radix FFT, output Re(0..n/2), Im(n/2-1..1).
+ * Only n = 256, m = 8 (the one size on the hot path) is implemented; other sizes abort(). */
+void rfft(float *x, int n, int m);
+
+/* ----------------------------------------------------------------------------------------------
+ * library state
+ * -------------------------------------------------------------------------------------------- */
+int sea_init(int device);            /* device < 0: keep the current HIP device */
+const char *sea_last_error(void);
+const char *sea_version(void);
+/* Device-resident constant tables, for callers that want to inspect them (tests). */
+int sea_tables_host(float *sigWindow200, float *irWindow17, float *idct25x25, int *melStart25,
+                    int *melLen25, float *melData25x16, float *hamming100, float *dct12x23,
+                    int *ccStart23, int *ccLen23, float *ccData23x32);
+int sea_gammatone_channels(float *cf64, float *bw64, float *midEar64);
+
+/* ----------------------------------------------------------------------------------------------
+ * (3) batch entry points, device pointers.  `stream` is a hipStream_t (NULL = default stream).
+ * Utterance u occupies samples [offsets[u], offsets[u]+lengths[u]) of d_in / d_out / d_out_f32;
+ * offsets must be multiples of 8 samples.
+ * -------------------------------------------------------------------------------------------- */
+/* NoiseSup over a batch (etsi_denoise semantics per utterance).
+ *   d_out_f32    optional: float NoiseSup output (pre-cast), same indexing as d_out
+ *   d_order      optional: launch order (utterance indices, longest first balances the tail)
+ *   d_first_out  optional: per utterance, frame index of the first output frame, -1 if none */
+int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
+                         const long long *d_offsets, const long long *d_lengths, const int *d_order,
+                         int *d_first_out, int n_utt, void *stream);
+/* rfft on [nframes][256] floats (d_out may equal d_in) */
+int sea_rfft256_batch(const float *d_in, float *d_out, long long nframes, void *stream);
+/* DoCompCeps on [nframes][201] floats (Data[-1..199]) -> [nframes][14] = c1..c12, c0, logE */
+int sea_compceps_frames(const float *d_data201, float *d_coef14, long long nframes, void *stream);
+/* CompCeps straight from the float NoiseSup stream of sea_ns_denoise_batch.  d_ceps_cum holds
+ * n_utt+1 prefix sums of per-utterance capacities (>= lengths/80 - 6 each); cepstral frame j of
+ * utterance u lands at d_ceps[(d_ceps_cum[u] + j) * 14]; d_n_ceps[u] receives the valid count. */
+int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const long long *d_lengths,
+                       const int *d_first_out, const long long *d_ceps_cum, long long total_frames,
+                       float *d_ceps, int *d_n_ceps, int n_utt, void *stream);
+/* 64-band gammatone resynthesis over a batch.  mask rows (64 floats) of utterance u start at row
+ * d_mask_offsets[u] and number (lengths[u]-320)/160+1.  d_inter is scratch of
+ * sea_resynth_scratch_bytes() bytes.  binary != 0 selects the ideal-binary-mask variant. */
+int sea_resynth64_batch(const short *d_in, short *d_out, const long long *d_offsets,
+                        const long long *d_lengths, const float *d_mask,
+                        const long long *d_mask_offsets, float *d_inter, const int *d_order,
+                        int n_utt, int binary, void *stream);
+long long sea_resynth_scratch_bytes(long long total_padded_samples);
+
+/* ----------------------------------------------------------------------------------------------
+ * (2) handle-based plug-in equivalents and host-buffer conveniences
+ * -------------------------------------------------------------------------------------------- */
+/* Many utterances at once from host memory: packs, uploads, runs one launch, downloads. */
+int sea_denoise_utterances(const short *const *in, short *const *out, const long *lengths, int n_utt);
+
+/* DoCompCeps(Data, Coef, This): Data[-1] must be valid (host pointers) */
+int sea_compceps_frame(const float *Data, float *Coef14);
+
+/* resynth(): in/out L samples, mask [F][64] with F=(L-320)/160+1 (host pointers) */
+int sea_resynth64(const short *in, long L, const float *mask, int F, int binary, short *out);
+/* gammaToneFilter(input, output, fChan, sigLength) for channel `chan` of the 64-band bank */
+int sea_gammatone_filter(const float *input, float *output, int chan, long sigLength);
+
+/* DoNoiseSupAlloc / DoNoiseSupInit / DoNoiseSup / DoNoiseSupDelete on a device-resident state */
+typedef struct sea_ns_stream sea_ns_stream;
+sea_ns_stream *sea_ns_stream_alloc(void);
+void sea_ns_stream_init(sea_ns_stream *s);
+/* consumes 80 float samples, returns 1 (TRUE) when out80 was produced, 0 during the latency */
+int sea_ns_stream_push(sea_ns_stream *s, const float *in80, float *out80);
+void sea_ns_stream_delete(sea_ns_stream *s);
+/* batched form on device pointers: n_streams independent streams x nframes frames of 80 floats,
+ * [stream][frame][80]; d_state holds sea_ns_state_floats() floats per stream and carries the
+ * recursion from call to call (reset != 0 starts from the DoNoiseSupInit state). */
+int sea_ns_streams_push(const float *d_in, float *d_out, int *d_produced, float *d_state, int n_streams,
+                        int nframes, int reset, void *stream);
+int sea_ns_state_floats(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

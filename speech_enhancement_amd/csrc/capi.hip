@@ -1,0 +1,457 @@
+/*
+ * capi.hip -- the C ABI of libsea_mi355x.so (include/sea_mi355x.h): context, launches, and the
+ * host-buffer drop-ins that keep the reference's own signatures.
+ */
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "../../include/sea_mi355x.h"
+#include "sea_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e_));            \
+    } while (0)
+
+struct DeviceCtx {
+    bool ready = false;
+    sea_ns_tables *ns = nullptr;
+    sea_cc_tables *cc = nullptr;
+    sea_gt_tables *gt = nullptr;
+};
+
+constexpr int kMaxDev = 64;
+DeviceCtx g_ctx[kMaxDev];
+std::mutex g_mu;
+sea_ns_tables g_ns_host;
+sea_cc_tables g_cc_host;
+sea_gt_tables g_gt_host;
+bool g_host_ready = false;
+
+void host_tables()
+{
+    if (g_host_ready) return;
+    sea_build_ns_tables(&g_ns_host);
+    sea_build_cc_tables(&g_cc_host);
+    sea_build_gt_tables(&g_gt_host);
+    g_host_ready = true;
+}
+
+/* per-device context for the CURRENT device; uploads the constant tables on first use */
+int ctx(DeviceCtx **out)
+{
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxDev) return fail("device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx &c = g_ctx[dev];
+    if (!c.ready) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail("device %d is %s; this library is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+        host_tables();
+        HIP_TRY(hipMalloc(&c.ns, sizeof(sea_ns_tables)));
+        HIP_TRY(hipMalloc(&c.cc, sizeof(sea_cc_tables)));
+        HIP_TRY(hipMalloc(&c.gt, sizeof(sea_gt_tables)));
+        HIP_TRY(hipMemcpy(c.ns, &g_ns_host, sizeof g_ns_host, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c.cc, &g_cc_host, sizeof g_cc_host, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c.gt, &g_gt_host, sizeof g_gt_host, hipMemcpyHostToDevice));
+        c.ready = true;
+    }
+    *out = &c;
+    return 0;
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n * sizeof(T) + 16); }
+};
+
+long long align8(long long v) { return (v + 7) & ~7LL; }
+
+} // namespace
+
+extern "C" {
+
+const char *sea_last_error(void) { return g_err; }
+const char *sea_version(void) { return "sea_mi355x 0.1 (gfx950)"; }
+
+int sea_init(int device)
+{
+    if (device >= 0) HIP_TRY(hipSetDevice(device));
+    DeviceCtx *c;
+    return ctx(&c);
+}
+
+int sea_tables_host(float *sigWindow200, float *irWindow17, float *idct25x25, int *melStart25,
+                    int *melLen25, float *melData25x16, float *hamming100, float *dct12x23,
+                    int *ccStart23, int *ccLen23, float *ccData23x32)
+{
+    sea_ns_plain_tables(sigWindow200, irWindow17, idct25x25, melStart25, melLen25, melData25x16);
+    sea_cc_plain_tables(hamming100, dct12x23, ccStart23, ccLen23, ccData23x32);
+    return 0;
+}
+
+int sea_gammatone_channels(float *cf64, float *bw64, float *midEar64)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    host_tables();
+    memcpy(cf64, g_gt_host.cf, sizeof g_gt_host.cf);
+    memcpy(bw64, g_gt_host.bw, sizeof g_gt_host.bw);
+    memcpy(midEar64, g_gt_host.midEar, sizeof g_gt_host.midEar);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
+                         const long long *d_offsets, const long long *d_lengths, const int *d_order,
+                         int *d_first_out, int n_utt, void *stream)
+{
+    if (n_utt <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    sea::NsBatchArgs a;
+    a.in = d_in;
+    a.out = d_out;
+    a.out_f32 = d_out_f32;
+    a.offsets = d_offsets;
+    a.lengths = d_lengths;
+    a.order = d_order;
+    a.first_out = d_first_out;
+    a.tables = c->ns;
+    a.n_utt = n_utt;
+    hipLaunchKernelGGL(sea::ns_denoise_kernel, dim3(n_utt), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sea_rfft256_batch(const float *d_in, float *d_out, long long nframes, void *stream)
+{
+    if (nframes <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    const long long grid = nframes < 65536 ? nframes : 65536;
+    hipLaunchKernelGGL(sea::rfft256_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream, d_in,
+                       d_out, nframes, &c->ns->fft);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sea_compceps_frames(const float *d_data201, float *d_coef14, long long nframes, void *stream)
+{
+    if (nframes <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    const long long grid = nframes < 65536 ? nframes : 65536;
+    hipLaunchKernelGGL(sea::compceps_frames_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
+                       d_data201, d_coef14, nframes, c->cc);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const long long *d_lengths,
+                       const int *d_first_out, const long long *d_ceps_cum, long long total_frames,
+                       float *d_ceps, int *d_n_ceps, int n_utt, void *stream)
+{
+    if (n_utt <= 0 || total_frames <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    sea::CepsArgs a;
+    a.den_f32 = d_den_f32;
+    a.offsets = d_offsets;
+    a.lengths = d_lengths;
+    a.first_out = d_first_out;
+    a.ceps_cum = d_ceps_cum;
+    a.ceps = d_ceps;
+    a.n_ceps = d_n_ceps;
+    a.tables = c->cc;
+    a.n_utt = n_utt;
+    const long long grid = total_frames < 131072 ? total_frames : 131072;
+    hipLaunchKernelGGL(sea::compceps_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+int sea_denoise_utterances(const short *const *in, short *const *out, const long *lengths, int n_utt)
+{
+    if (n_utt <= 0) return 0;
+    std::vector<long long> offs(n_utt), lens(n_utt);
+    long long total = 0;
+    for (int u = 0; u < n_utt; ++u) {
+        if (lengths[u] < 0) return fail("negative length for utterance %d", u);
+        offs[u] = total;
+        lens[u] = lengths[u];
+        total += align8(lengths[u]);
+    }
+    if (total == 0) return 0;
+    std::vector<short> pack((size_t)total, 0);
+    for (int u = 0; u < n_utt; ++u) memcpy(&pack[(size_t)offs[u]], in[u], (size_t)lens[u] * sizeof(short));
+
+    DevBuf<short> din, dout;
+    DevBuf<long long> doffs, dlens;
+    HIP_TRY(din.alloc((size_t)total));
+    HIP_TRY(dout.alloc((size_t)total));
+    HIP_TRY(doffs.alloc(n_utt));
+    HIP_TRY(dlens.alloc(n_utt));
+    HIP_TRY(hipMemcpy(din.p, pack.data(), (size_t)total * sizeof(short), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(doffs.p, offs.data(), n_utt * sizeof(long long), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dlens.p, lens.data(), n_utt * sizeof(long long), hipMemcpyHostToDevice));
+    if (sea_ns_denoise_batch(din.p, dout.p, nullptr, doffs.p, dlens.p, nullptr, nullptr, n_utt, nullptr)) return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(pack.data(), dout.p, (size_t)total * sizeof(short), hipMemcpyDeviceToHost));
+    for (int u = 0; u < n_utt; ++u) /* the trailing partial frame stays untouched */
+        memcpy(out[u], &pack[(size_t)offs[u]], (size_t)(lens[u] / 80 * 80) * sizeof(short));
+    return 0;
+}
+
+int etsi_denoise(short *p_data, short *p_denoised, long i_frame)
+{
+    const short *in[1] = {p_data};
+    short *out[1] = {p_denoised};
+    long len[1] = {i_frame};
+    if (sea_denoise_utterances(in, out, len, 1)) {
+        fprintf(stderr, "ERROR:   etsi_denoise (MI355X): %s\r\n", g_err);
+        return 1; /* TRUE == fault, AdvFrontEnd.c:207-209 */
+    }
+    return 0;
+}
+
+int etsi_denoise_synchronization(short *p_data, short *p_denoised, long i_frame)
+{ /* AdvFrontEnd.c:213-226: copies out only when etsi_denoise reports a fault */
+    std::vector<short> tmp((size_t)(i_frame > 0 ? i_frame : 1));
+    (void)p_denoised;
+    return etsi_denoise(p_data, tmp.data(), i_frame);
+}
+
+int etsi_denoise_16k(short *p_data, short *p_denoised, long i_frame)
+{
+    (void)p_data;
+    (void)p_denoised;
+    (void)i_frame;
+    fprintf(stderr, "ERROR:   etsi_denoise_16k: the reference's 16 kHz mode is defective (heap over-read) and is not provided\r\n");
+    return fail("etsi_denoise_16k is not provided");
+}
+
+int etsi_denoise_16k_synchronization(short *p_data, short *p_denoised, long i_frame)
+{ /* AdvFrontEnd.c:316-329 calls the 8 kHz-mode etsi_denoise, exactly like the non-16k twin */
+    return etsi_denoise_synchronization(p_data, p_denoised, i_frame);
+}
+
+void rfft(float *x, int n, int m)
+{
+    if (n != 256 || m != 8) {
+        fprintf(stderr, "ERROR:   rfft (MI355X): only n=256, m=8 is implemented (got n=%d, m=%d)\r\n", n, m);
+        abort();
+    }
+    DevBuf<float> d;
+    bool ok = d.alloc(256) == hipSuccess && hipMemcpy(d.p, x, 256 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+              sea_rfft256_batch(d.p, d.p, 1, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess &&
+              hipMemcpy(x, d.p, 256 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) {
+        fprintf(stderr, "ERROR:   rfft (MI355X): no usable gfx950 device: %s\r\n", g_err);
+        abort();
+    }
+}
+
+int sea_compceps_frame(const float *Data, float *Coef14)
+{
+    DevBuf<float> din, dout;
+    HIP_TRY(din.alloc(201));
+    HIP_TRY(dout.alloc(14));
+    HIP_TRY(hipMemcpy(din.p, Data - 1, 201 * sizeof(float), hipMemcpyHostToDevice));
+    if (sea_compceps_frames(din.p, dout.p, 1, nullptr)) return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(Coef14, dout.p, 14 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+long long sea_resynth_scratch_bytes(long long total_padded_samples)
+{
+    return total_padded_samples * 64 * (long long)sizeof(float);
+}
+
+int sea_resynth64_batch(const short *d_in, short *d_out, const long long *d_offsets,
+                        const long long *d_lengths, const float *d_mask,
+                        const long long *d_mask_offsets, float *d_inter, const int *d_order,
+                        int n_utt, int binary, void *stream)
+{
+    if (n_utt <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    sea::ResynthArgs a;
+    a.in = d_in;
+    a.out = d_out;
+    a.offsets = d_offsets;
+    a.lengths = d_lengths;
+    a.mask = d_mask;
+    a.mask_offsets = d_mask_offsets;
+    a.inter = d_inter;
+    a.order = d_order;
+    a.tables = c->gt;
+    a.n_utt = n_utt;
+    a.binary = binary;
+    hipLaunchKernelGGL(sea::resynth_fwd_kernel, dim3(n_utt), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(sea::resynth_bwd_kernel, dim3(n_utt), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sea_resynth64(const short *in, long L, const float *mask, int F, int binary, short *out)
+{
+    if (L < 320) return fail("resynth64: L=%ld is shorter than one 320-sample window", L);
+    if (F != (int)((L - 320) / 160 + 1)) return fail("resynth64: F=%d does not match L=%ld", F, L);
+    const long long Lp = align8(L);
+    DevBuf<short> din, dout;
+    DevBuf<float> dmask, dinter;
+    DevBuf<long long> dmeta;
+    HIP_TRY(din.alloc((size_t)Lp));
+    HIP_TRY(dout.alloc((size_t)Lp));
+    HIP_TRY(dmask.alloc((size_t)F * 64));
+    HIP_TRY(dinter.alloc((size_t)Lp * 64));
+    HIP_TRY(dmeta.alloc(3));
+    const long long meta[3] = {0, L, 0};
+    HIP_TRY(hipMemcpy(din.p, in, (size_t)L * sizeof(short), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dmask.p, mask, (size_t)F * 64 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dmeta.p, meta, sizeof meta, hipMemcpyHostToDevice));
+    if (sea_resynth64_batch(din.p, dout.p, dmeta.p, dmeta.p + 1, dmask.p, dmeta.p + 2, dinter.p, nullptr, 1,
+                            binary, nullptr))
+        return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)L * sizeof(short), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sea_gammatone_filter(const float *input, float *output, int chan, long sigLength)
+{
+    if (chan < 0 || chan >= 64) return fail("gammatone: channel %d out of range", chan);
+    if (sigLength <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    DevBuf<float> din, dout;
+    HIP_TRY(din.alloc((size_t)sigLength));
+    HIP_TRY(dout.alloc((size_t)sigLength));
+    HIP_TRY(hipMemcpy(din.p, input, (size_t)sigLength * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sea::gammatone_kernel, dim3(1), dim3(64), 0, nullptr, din.p, dout.p, chan,
+                       (long long)sigLength, c->gt);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(output, dout.p, (size_t)sigLength * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+struct sea_ns_stream {
+    float *state = nullptr;  /* kNsStateFloats */
+    float *io = nullptr;     /* 80 in + 80 out */
+    int *produced = nullptr;
+    int fresh = 1;
+};
+
+sea_ns_stream *sea_ns_stream_alloc(void)
+{ /* DoNoiseSupAlloc, NoiseSup.c:859-868: NULL on allocation failure */
+    sea_ns_stream *s = new (std::nothrow) sea_ns_stream();
+    if (!s) return nullptr;
+    if (hipMalloc(&s->state, sea::kNsStateFloats * sizeof(float)) != hipSuccess ||
+        hipMalloc(&s->io, 160 * sizeof(float)) != hipSuccess || hipMalloc(&s->produced, sizeof(int)) != hipSuccess) {
+        fail("sea_ns_stream_alloc: hipMalloc failed");
+        sea_ns_stream_delete(s);
+        return nullptr;
+    }
+    return s;
+}
+
+void sea_ns_stream_init(sea_ns_stream *s)
+{ /* DoNoiseSupInit, NoiseSup.c:884-1009: the next push starts from the initial state */
+    if (s) s->fresh = 1;
+}
+
+int sea_ns_stream_push(sea_ns_stream *s, const float *in80, float *out80)
+{
+    DeviceCtx *c;
+    if (!s || ctx(&c)) {
+        fprintf(stderr, "ERROR:   DoNoiseSup (MI355X): %s\r\n", s ? g_err : "NULL stream");
+        exit(0); /* the reference's DoNoiseSup path ends the process on failure (NoiseSup.c:983-987) */
+    }
+    sea::NsStreamArgs a;
+    a.in = s->io;
+    a.out = s->io + 80;
+    a.produced = s->produced;
+    a.state = s->state;
+    a.tables = c->ns;
+    a.nframes = 1;
+    a.reset = s->fresh;
+    int produced = 0;
+    bool ok = hipMemcpy(s->io, in80, 80 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(sea::ns_stream_kernel, dim3(1), dim3(64), 0, nullptr, a);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+             hipMemcpy(&produced, s->produced, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (ok && produced) ok = hipMemcpy(out80, s->io + 80, 80 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) {
+        fprintf(stderr, "ERROR:   DoNoiseSup (MI355X): device failure\r\n");
+        exit(0);
+    }
+    s->fresh = 0;
+    return produced;
+}
+
+void sea_ns_stream_delete(sea_ns_stream *s)
+{
+    if (!s) return;
+    if (s->state) (void)hipFree(s->state);
+    if (s->io) (void)hipFree(s->io);
+    if (s->produced) (void)hipFree(s->produced);
+    delete s;
+}
+
+/* batched form of the above on device pointers: B streams x nframes frames */
+int sea_ns_streams_push(const float *d_in, float *d_out, int *d_produced, float *d_state, int n_streams,
+                        int nframes, int reset, void *stream)
+{
+    if (n_streams <= 0 || nframes <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    sea::NsStreamArgs a;
+    a.in = d_in;
+    a.out = d_out;
+    a.produced = d_produced;
+    a.state = d_state;
+    a.tables = c->ns;
+    a.nframes = nframes;
+    a.reset = reset;
+    hipLaunchKernelGGL(sea::ns_stream_kernel, dim3(n_streams), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sea_ns_state_floats(void) { return sea::kNsStateFloats; }
+
+} // extern "C"

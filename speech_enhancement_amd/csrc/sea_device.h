@@ -1,0 +1,158 @@
+/*
+ * sea_device.h -- device-side building blocks shared by the gfx950 kernels.
+ *
+ * Everything here is written for ONE 64-lane wavefront working on one frame / one utterance with
+ * its scratch in LDS.  The arithmetic reproduces the reference C expression by expression
+ * (compile with -ffp-contract=off: no FMA may be formed from a*b+c), while the distribution of the
+ * work over lanes is this engine's own.
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sea_tables.h"
+
+namespace sea {
+
+constexpr int kLanes = 64;
+
+/* LDS traffic inside a single wave is executed in program order by the hardware; what has to be
+ * prevented is the compiler moving a lane's read above another lane's write.  With 64-thread
+ * workgroups __syncthreads() lowers to exactly that (a wave-local fence, no cross-wave wait). */
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+/* per-lane constants of the FFT schedule (sea_fft_tables), loaded once, kept in VGPRs */
+struct FftRegs {
+    unsigned flags;
+    unsigned item[SEA_FFT_LSTAGES];
+    float tw[SEA_FFT_LSTAGES][4];
+};
+
+__device__ __forceinline__ void load_fft_regs(FftRegs &R, const sea_fft_tables *t, int lane)
+{
+    R.flags = t->fftFlags[lane];
+#pragma unroll
+    for (int s = 0; s < SEA_FFT_LSTAGES; ++s) {
+        R.item[s] = t->fftItem[s][lane];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) R.tw[s][k] = t->fftTw[s][k][lane];
+    }
+}
+
+/* One split-radix level n2 = 8<<S: every lane executes at most one butterfly (its work item).
+ * Arithmetic: etsi/cpp/rfft.c:110-113 (plain), :120-125 (pi/4), :145-174 (twiddled). */
+template <int S>
+__device__ __forceinline__ void fft_level(float *work, const FftRegs &R)
+{
+    constexpr int n4 = 2 << S;
+    const unsigned it = R.item[S];
+    const unsigned kind = it >> 16;
+    const int a = (int)(it & 255u);
+    if (kind == SEA_BF_TWIDDLE) {
+        const int b = (int)((it >> 8) & 255u);
+        const float cc1 = R.tw[S][0], ss1 = R.tw[S][1], cc3 = R.tw[S][2], ss3 = R.tw[S][3];
+        const float x1 = work[a], x2 = work[a + n4], x3 = work[a + 2 * n4], x4 = work[a + 3 * n4];
+        const float x5 = work[b], x6 = work[b + n4], x7 = work[b + 2 * n4], x8 = work[b + 3 * n4];
+        float t1 = x3 * cc1 + x7 * ss1;
+        float t2 = x7 * cc1 - x3 * ss1;
+        float t3 = x4 * cc3 + x8 * ss3;
+        float t4 = x8 * cc3 - x4 * ss3;
+        const float t5 = t1 + t3, t6 = t2 + t4;
+        t3 = t1 - t3;
+        t4 = t2 - t4;
+        work[a + 2 * n4] = t6 - x6;  /* x[i3] */
+        work[b + 3 * n4] = x6 + t6;  /* x[i8] */
+        work[b + 2 * n4] = -x2 - t3; /* x[i7] */
+        work[a + 3 * n4] = x2 - t3;  /* x[i4] */
+        work[b + n4] = x1 - t5;      /* x[i6] */
+        work[a] = x1 + t5;           /* x[i1] */
+        work[b] = x5 - t4;           /* x[i5] */
+        work[a + n4] = x5 + t4;      /* x[i2] */
+    } else if (kind == SEA_BF_PLAIN) {
+        const float x1 = work[a], x3 = work[a + 2 * n4], x4 = work[a + 3 * n4];
+        const float t1 = x4 + x3;
+        work[a + 3 * n4] = x4 - x3;
+        work[a + 2 * n4] = x1 - t1;
+        work[a] = x1 + t1;
+    } else if (kind == SEA_BF_PI4) {
+        const float x1 = work[a], x2 = work[a + n4], x3 = work[a + 2 * n4], x4 = work[a + 3 * n4];
+        /* float sum, then a DOUBLE division by M_SQRT2, rounded back to float */
+        const float t1 = (float)((double)(x3 + x4) / 1.41421356237309504880);
+        const float t2 = (float)((double)(x3 - x4) / 1.41421356237309504880);
+        work[a + 3 * n4] = x2 - t1;
+        work[a + 2 * n4] = -x2 - t1;
+        work[a + n4] = x1 - t2;
+        work[a] = x1 + t2;
+    }
+}
+
+/* 256-point real split-radix FFT of one frame held 4 elements per lane: lane l passes elements
+ * l, l+64, l+128, l+192 (already windowed / zero padded).  Result is left in work[0..255] in the
+ * reference's order Re(0..128), Im(127..1) (etsi/cpp/rfft.c:27-29).  Ends with a wave_sync(). */
+__device__ __forceinline__ void rfft256(float e0, float e1, float e2, float e3, float *work,
+                                        const FftRegs &R, int lane)
+{
+    /* bit reversal: positions 4r..4r+3 (r = bitrev6(lane)) take elements l, l+128, l+64, l+192 */
+    float g0 = e0, g1 = e2, g2 = e1, g3 = e3;
+    {   /* length-two butterflies (rfft.c:82-96) */
+        const float s01 = g0 + g1, d01 = g0 - g1, s23 = g2 + g3, d23 = g2 - g3;
+        const bool f0 = (R.flags & 1u) != 0, f1 = (R.flags & 2u) != 0;
+        g0 = f0 ? s01 : g0;
+        g1 = f0 ? d01 : g1;
+        g2 = f1 ? s23 : g2;
+        g3 = f1 ? d23 : g3;
+    }
+    {   /* n2 = 4 level: plain butterfly only (rfft.c:110-113) */
+        const float t1 = g3 + g2;
+        const float n3 = g3 - g2, n2 = g0 - t1, n0 = g0 + t1;
+        const bool f = (R.flags & 4u) != 0;
+        g3 = f ? n3 : g3;
+        g2 = f ? n2 : g2;
+        g0 = f ? n0 : g0;
+    }
+    const int r = (int)(__brev((unsigned)lane) >> 26);
+    *reinterpret_cast<float4 *>(work + 4 * r) = make_float4(g0, g1, g2, g3);
+    wave_sync();
+    fft_level<0>(work, R);
+    wave_sync();
+    fft_level<1>(work, R);
+    wave_sync();
+    fft_level<2>(work, R);
+    wave_sync();
+    fft_level<3>(work, R);
+    wave_sync();
+    fft_level<4>(work, R);
+    wave_sync();
+    fft_level<5>(work, R);
+    wave_sync();
+}
+
+/* float -> int16 exactly as the reference's (short) cast behaves on x86-64: truncate toward zero
+ * to int32 and keep the low 16 bits; out-of-int32-range gives 0 (etsi/cpp/ParmInterface.c:266). */
+__device__ __forceinline__ int cast_i16(float v)
+{
+    const bool ok = (v > -2147483648.0f) && (v < 2147483648.0f);
+    const int i = ok ? (int)v : 0;
+    return i & 0xFFFF;
+}
+
+/* sum init + p[0] + p[1] + ... + p[n-1] in exactly that order (all lanes compute the same value).
+ * p must be 16-byte aligned and padded to a multiple of 4 floats. */
+template <int N>
+__device__ __forceinline__ float serial_sum(const float *p, float init)
+{
+    float acc = init;
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+        const float4 v = *reinterpret_cast<const float4 *>(p + 4 * i);
+        acc += v.x;
+        acc += v.y;
+        acc += v.z;
+        acc += v.w;
+    }
+#pragma unroll
+    for (int i = N / 4 * 4; i < N; ++i) acc += p[i];
+    return acc;
+}
+
+} // namespace sea

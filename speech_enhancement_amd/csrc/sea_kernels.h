@@ -1,0 +1,74 @@
+/*
+ * sea_kernels.h -- kernel argument blocks and launch prototypes (internal to the library).
+ */
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sea_tables.h"
+
+namespace sea {
+
+/* Batch of utterances packed in one int16 buffer.  offsets[u] (in samples, multiple of 8) locates
+ * utterance u in `in`, `out` and `out_f32`; lengths[u] is its sample count. */
+struct NsBatchArgs {
+    const int16_t *in;
+    int16_t *out;
+    float *out_f32;            /* optional: float NoiseSup output stream, same indexing as out */
+    const long long *offsets;
+    const long long *lengths;
+    const int *order;          /* optional: block b processes utterance order[b] (longest first) */
+    int *first_out;            /* optional: per utterance, frame index of the first NS output (-1: none) */
+    const sea_ns_tables *tables;
+    int n_utt;
+};
+
+/* B independent streams, nframes frames of 80 floats each, state blobs of kNsStateFloats floats */
+constexpr int kNsStateFloats = 2 * 320 + 12 * 64 + 32;
+struct NsStreamArgs {
+    const float *in;           /* [B][nframes][80] */
+    float *out;                /* [B][nframes][80], written where produced */
+    int *produced;             /* [B][nframes] */
+    float *state;              /* [B][kNsStateFloats] */
+    const sea_ns_tables *tables;
+    int nframes;
+    int reset;                 /* 1: start from DoNoiseSupInit state instead of loading */
+};
+
+struct CepsArgs {
+    const float *den_f32;      /* float NoiseSup stream written by ns_denoise_kernel */
+    const long long *offsets;  /* as above */
+    const long long *lengths;
+    const int *first_out;
+    const long long *ceps_cum; /* n_utt+1 prefix sums of the per-utterance frame capacity */
+    float *ceps;               /* [ceps_cum[n_utt]][14] */
+    int *n_ceps;               /* optional: valid cepstral frames per utterance */
+    const sea_cc_tables *tables;
+    int n_utt;
+};
+
+struct ResynthArgs {
+    const int16_t *in;
+    int16_t *out;
+    const long long *offsets;      /* samples, multiple of 8 */
+    const long long *lengths;
+    const float *mask;             /* rows of 64 floats */
+    const long long *mask_offsets; /* in rows */
+    float *inter;                  /* intermediate [sum(lengths padded)][64] floats */
+    const int *order;
+    const sea_gt_tables *tables;
+    int n_utt;
+    int binary;
+};
+
+__global__ void ns_denoise_kernel(NsBatchArgs a);
+__global__ void ns_stream_kernel(NsStreamArgs a);
+__global__ void rfft256_kernel(const float *in, float *out, long long nframes, const sea_fft_tables *t);
+__global__ void compceps_kernel(CepsArgs a);
+__global__ void compceps_frames_kernel(const float *data201, float *coef14, long long nframes,
+                                       const sea_cc_tables *t);
+__global__ void resynth_fwd_kernel(ResynthArgs a);
+__global__ void resynth_bwd_kernel(ResynthArgs a);
+__global__ void gammatone_kernel(const float *in, float *out, int chan, long long L, const sea_gt_tables *t);
+
+} // namespace sea

@@ -1,0 +1,357 @@
+/*
+ * sea_tables.c -- host-side construction of the engine's constant tables.
+ *
+ * MUST be compiled as C with gcc -O2 -ffp-contract=off (csrc/Makefile does): the values have to
+ * be bit-identical to what the reference's init code computes, and that depends on which
+ * sub-expressions are float and which are double.  Each builder cites the reference code whose
+ * arithmetic it reproduces; the layouts (lane-major, padded, bit-reversed) are this engine's own.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "sea_tables.h"
+
+static const double kTwoPi = 6.28318530717958647692; /* PIx2, etsi/cpp/ParmInterface.h:45 */
+static const double kPi = 3.14159265358979323846;    /* M_PI, etsi/cpp/rfft.h:16; PI CompCeps.c:31 */
+
+/* ------------------------------------------------------------------------------------------
+ * Split-radix schedule for N = 256 (etsi/cpp/rfft.c:45-180)
+ * ---------------------------------------------------------------------------------------- */
+static unsigned bitrev(unsigned v, int bits)
+{
+    unsigned r = 0;
+    int b;
+    for (b = 0; b < bits; b++)
+        if (v & (1u << b)) r |= 1u << (bits - 1 - b);
+    return r;
+}
+
+/* Calls visit(base, ctx) for every block start the reference's "is/id" double loop selects for
+ * block length n2 at FFT size n (rfft.c:107-130 and its twins). */
+static void for_each_block(int n, int n2, int first_is_adjust, void (*visit)(int, void *), void *ctx)
+{
+    int is = 0, id = n2 << 1, i;
+    while (is < n - first_is_adjust) {
+        for (i = is; i < n; i += id) visit(i, ctx);
+        is = (id << 1) - n2;
+        id <<= 2;
+    }
+}
+
+typedef struct {
+    unsigned char mark[SEA_NFFT];
+} mark_ctx;
+static void mark_visit(int i, void *ctx) { ((mark_ctx *)ctx)->mark[i] = 1; }
+
+typedef struct {
+    int base[64], n;
+} list_ctx;
+static void list_visit(int i, void *ctx)
+{
+    list_ctx *l = (list_ctx *)ctx;
+    l->base[l->n++] = i;
+}
+
+static void build_fft(sea_fft_tables *f)
+{
+    mark_ctx len2, len4;
+    int lane, s;
+    memset(f, 0, sizeof *f);
+    memset(&len2, 0, sizeof len2);
+    memset(&len4, 0, sizeof len4);
+    /* length-two butterflies: rfft.c:82-96 (is=0,id=4; is=2id-2) == blocks of "n2 = 2" */
+    for_each_block(SEA_NFFT, 2, 1, mark_visit, &len2);
+    /* first L level, n2 = 4: only the plain butterfly exists (n4 == 1): rfft.c:100-113 */
+    for_each_block(SEA_NFFT, 4, 0, mark_visit, &len4);
+    for (lane = 0; lane < SEA_LANES; lane++) {
+        int g = 4 * (int)bitrev((unsigned)lane, 6);
+        f->fftFlags[lane] = (len2.mark[g] ? 1u : 0u) | (len2.mark[g + 2] ? 2u : 0u) | (len4.mark[g] ? 4u : 0u);
+    }
+    /* levels n2 = 8 .. 256: one work item per lane, twiddle items first */
+    for (s = 0; s < SEA_FFT_LSTAGES; s++) {
+        int n2 = 8 << s, n4 = n2 >> 2, n8 = n2 >> 3, b, j, slot = 0;
+        float e = (float)((kPi * 2) / n2); /* rfft.c:105 */
+        list_ctx blocks;
+        blocks.n = 0;
+        for_each_block(SEA_NFFT, n2, 0, list_visit, &blocks);
+        for (j = 1; j < n8; j++) {
+            float a = j * e, a3 = 3 * a; /* rfft.c:133-138: float angles, double cos/sin */
+            float cc1 = (float)cos((double)a), ss1 = (float)sin((double)a);
+            float cc3 = (float)cos((double)a3), ss3 = (float)sin((double)a3);
+            for (b = 0; b < blocks.n; b++, slot++) {
+                unsigned i1 = (unsigned)(blocks.base[b] + j), i5 = (unsigned)(blocks.base[b] + n4 - j);
+                f->fftItem[s][slot] = ((unsigned)SEA_BF_TWIDDLE << 16) | (i5 << 8) | i1;
+                f->fftTw[s][0][slot] = cc1;
+                f->fftTw[s][1][slot] = ss1;
+                f->fftTw[s][2][slot] = cc3;
+                f->fftTw[s][3][slot] = ss3;
+            }
+        }
+        for (b = 0; b < blocks.n; b++, slot++)
+            f->fftItem[s][slot] = ((unsigned)SEA_BF_PLAIN << 16) | (unsigned)blocks.base[b];
+        for (b = 0; b < blocks.n; b++, slot++)
+            f->fftItem[s][slot] = ((unsigned)SEA_BF_PI4 << 16) | (unsigned)(blocks.base[b] + n8);
+        if (slot > SEA_LANES) abort();
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Mel filter banks
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int start, len;
+    float w[32];
+} band_t;
+
+static float hz_to_mel(float hz) { return (float)(2595.0 * log10(1.0 + hz / 700.0)); }
+
+/* mel-spaced FFT bin for fraction num/den of the way from lo_mel to hi_mel:
+ * MelProc.c:147-150 and :421-424 */
+static int mel_bin(float lo_mel, float hi_mel, int num, int den, int nfft, float fs)
+{
+    float mel = lo_mel + (float)num / den * (hi_mel - lo_mel);
+    float hz = (float)(700 * (pow(10, mel / 2595.0) - 1.0));
+    return (int)(nfft * hz / fs + 0.5);
+}
+
+/* 25 normalised triangles for the Wiener filter design: InitMelFBwindows(.., 0.0, 8000, 128, 25, 1)
+ * called at NoiseSup.c:988; arithmetic of MelProc.c:128-230 */
+static void wiener_bands(band_t *B)
+{
+    const float fs = 8000.0f;
+    int c[SEA_NMEL], i, j;
+    float lo = hz_to_mel(0.0f), hi = hz_to_mel(fs / 2);
+    for (i = 0; i < SEA_NMEL; i++) c[i] = mel_bin(lo, hi, i, SEA_NMEL - 1, 128, fs);
+    for (i = 0; i < SEA_NMEL; i++) {
+        band_t *b = &B[i];
+        float area = 0.0f;
+        int rise = (i > 0) ? c[i] - c[i - 1] : 0;
+        int fall = (i < SEA_NMEL - 1) ? c[i + 1] - c[i] : 0;
+        int n = 0;
+        memset(b, 0, sizeof *b);
+        if (i == 0) { /* falling edge only, starts at its own centre */
+            b->start = c[0];
+            for (j = 0; j < fall; j++) b->w[n++] = (float)(1.0 - (float)j / (float)fall);
+        } else {
+            b->start = c[i - 1] + 1;
+            for (j = 0; j < rise; j++) b->w[n++] = (float)(j + 1) / (float)rise;
+            for (j = 0; j < fall - 1; j++) b->w[n++] = (float)(1.0 - (j + 1) / (float)fall);
+        }
+        b->len = n;
+        for (j = 0; j < n; j++) area += b->w[j];
+        for (j = 0; j < n; j++) b->w[j] /= area;
+    }
+}
+
+/* 23 un-normalised triangles for the cepstrum: InitFFTWindows(.., 64.0, 8000, 256, 23) +
+ * ComputeTriangle, called at CompCeps.c:283-286; arithmetic of MelProc.c:402-522 */
+static void cepstral_bands(band_t *B)
+{
+    const float fs = 8000.0f;
+    float lo = hz_to_mel(64.0f), hi = hz_to_mel(fs / 2);
+    int i, j, top_prev = 0;
+    for (i = 0; i < SEA_CC_NCHAN; i++) {
+        memset(&B[i], 0, sizeof B[i]);
+        B[i].start = mel_bin(lo, hi, i, SEA_CC_NCHAN + 1, 256, fs);
+        B[i].len = mel_bin(lo, hi, i + 2, SEA_CC_NCHAN + 1, 256, fs) - B[i].start + 1;
+    }
+    for (i = 0; i < SEA_CC_NCHAN; i++) {
+        band_t *b = &B[i];
+        int up = ((i + 1 < SEA_CC_NCHAN) ? B[i + 1].start : top_prev) - b->start + 1;
+        int down = b->len - up + 1;
+        for (j = 0; j < up; j++) b->w[j] = (float)(j + 1) / up;
+        for (j = 1; j < down; j++) b->w[up + j - 1] = (float)(down - j) / down;
+        top_prev = b->start + b->len - 1;
+    }
+}
+
+/* mel-warped inverse DCT basis: InitMelIDCTbasis(.., 25, 8000, 128), MelProc.c:283-337 */
+static void wiener_idct(const band_t *B, float basis[SEA_NMEL][SEA_NMEL])
+{
+    const int fs = 8000;
+    const float step = fs / (float)128;
+    float centre[SEA_NMEL], width[SEA_NMEL];
+    int f, t, i;
+    for (f = 0; f < SEA_NMEL; f++) {
+        if (f == 0)
+            centre[f] = B[f].start * step;
+        else if (f == SEA_NMEL - 1)
+            centre[f] = (B[f].start + B[f].len - 1) * step;
+        else {
+            float origin = B[f].start * step, mass = 0.0f, moment = 0.0f;
+            for (i = 0; i < B[f].len; i++) {
+                moment += B[f].w[i] * (origin + i * step);
+                mass += B[f].w[i];
+            }
+            centre[f] = moment / mass;
+        }
+    }
+    for (f = 0; f < SEA_NMEL; f++) {
+        int a = (f == 0) ? 0 : f - 1, b = (f == SEA_NMEL - 1) ? f : f + 1;
+        width[f] = (centre[b] - centre[a]) / fs;
+    }
+    for (t = 0; t < SEA_NMEL; t++)
+        for (f = 0; f < SEA_NMEL; f++) basis[t][f] = (float)(width[f] * cos(kTwoPi * t * centre[f] / fs));
+}
+
+static float hanning(int i, int n)
+{ /* NoiseSup.c:975 / :979 */
+    return (float)(0.5 - 0.5 * cos((kTwoPi * ((float)i + 0.5)) / (float)(short)n));
+}
+
+static float hamming_half(int i)
+{ /* CompCeps.c:92-93, i < 100 */
+    return (float)(0.54 - 0.46 * cos(kTwoPi * (i + 0.5) / (short)SEA_WIN));
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Public builders
+ * ---------------------------------------------------------------------------------------- */
+void sea_build_ns_tables(sea_ns_tables *t)
+{
+    band_t B[SEA_NMEL];
+    float basis[SEA_NMEL][SEA_NMEL];
+    int lane, k, f, j;
+    memset(t, 0, sizeof *t);
+    build_fft(&t->fft);
+    wiener_bands(B);
+    wiener_idct(B, basis);
+    for (lane = 0; lane < SEA_LANES; lane++)
+        for (k = 0; k < 4; k++) {
+            int i = lane + 64 * k;
+            t->win[k][lane] = (i < SEA_WIN) ? hanning(i, SEA_WIN) : 0.0f;
+        }
+    for (f = 0; f < SEA_NMEL; f++) {
+        if (B[f].len > SEA_MEL_TAPS) abort();
+        t->melStart[f] = B[f].start;
+        t->melLen[f] = B[f].len;
+        for (j = 0; j < B[f].len; j++) t->melW[j][f] = B[f].w[j];
+    }
+    for (f = 0; f < SEA_NMEL; f++)
+        for (lane = 0; lane <= 8; lane++) t->idct[f][lane] = basis[lane][f];
+    for (lane = 0; lane <= 8; lane++) t->irWin[lane] = hanning(8 + lane, SEA_NTAP);
+    t->eps = (float)exp(-10.0); /* NS_EPS, NoiseSup.h:32 */
+}
+
+void sea_build_cc_tables(sea_cc_tables *t)
+{
+    band_t B[SEA_CC_NCHAN];
+    int lane, k, f, j, i;
+    memset(t, 0, sizeof *t);
+    build_fft(&t->fft);
+    cepstral_bands(B);
+    for (lane = 0; lane < SEA_LANES; lane++)
+        for (k = 0; k < 4; k++) {
+            i = lane + 64 * k;
+            t->win[k][lane] = (i < SEA_WIN) ? hamming_half(i < SEA_WIN / 2 ? i : SEA_WIN - 1 - i) : 0.0f;
+        }
+    for (f = 0; f < SEA_CC_NCHAN; f++) {
+        if (B[f].len > SEA_CC_TAPS) abort();
+        t->melStart[f] = B[f].start;
+        t->melLen[f] = B[f].len;
+        for (j = 0; j < B[f].len; j++) t->melW[j][f] = B[f].w[j];
+    }
+    /* InitDCTMatrix(13, 23): CompCeps.c:153-173 */
+    for (i = 1; i <= 12; i++)
+        for (j = 0; j < SEA_CC_NCHAN; j++)
+            t->dct[j][i - 1] = (float)cos(kPi * (float)i / (float)SEA_CC_NCHAN * ((float)j + 0.5));
+    t->floorFB = (float)exp((double)-10.0); /* CompCeps.c:405-406 */
+    t->floorE = (float)exp((double)-50.0);
+}
+
+void sea_ns_plain_tables(float *sigWindow200, float *irWindow17, float *idct25x25, int *melStart25,
+                         int *melLen25, float *melData)
+{
+    band_t B[SEA_NMEL];
+    float basis[SEA_NMEL][SEA_NMEL];
+    int i, f;
+    wiener_bands(B);
+    wiener_idct(B, basis);
+    for (i = 0; i < SEA_WIN; i++) sigWindow200[i] = hanning(i, SEA_WIN);
+    for (i = 0; i < SEA_NTAP; i++) irWindow17[i] = hanning(i, SEA_NTAP);
+    memcpy(idct25x25, basis, sizeof basis);
+    for (f = 0; f < SEA_NMEL; f++) {
+        melStart25[f] = B[f].start;
+        melLen25[f] = B[f].len;
+        for (i = 0; i < B[f].len && i < 16; i++) melData[f * 16 + i] = B[f].w[i];
+    }
+}
+
+void sea_cc_plain_tables(float *hamming100, float *dct12x23, int *melStart23, int *melLen23, float *melData)
+{
+    band_t B[SEA_CC_NCHAN];
+    int i, j, f;
+    cepstral_bands(B);
+    for (i = 0; i < SEA_WIN / 2; i++) hamming100[i] = hamming_half(i);
+    for (i = 1; i <= 12; i++)
+        for (j = 0; j < SEA_CC_NCHAN; j++)
+            dct12x23[(i - 1) * SEA_CC_NCHAN + j] = (float)cos(kPi * (float)i / (float)SEA_CC_NCHAN * ((float)j + 0.5));
+    for (f = 0; f < SEA_CC_NCHAN; f++) {
+        melStart23[f] = B[f].start;
+        melLen23[f] = B[f].len;
+        for (i = 0; i < B[f].len && i < 32; i++) melData[f * 32 + i] = B[f].w[i];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Gammatone bank: resyth_64sub_ori/cpp/extractwav.cpp:41-54 (channel constants),
+ * :133-166 + :258-278 (BS3383 middle-ear curve), :176-183 (filter coefficients),
+ * :95-107 (raised-cosine overlap-add halves).  The reference is C++: exp/cos/sin of float
+ * arguments resolve to the float overloads, pow() to double.
+ * ---------------------------------------------------------------------------------------- */
+static const float kEarF[29] = {20.0,  25.0,  31.5,   40.0,   50.0,   63.0,   80.0,   100.0,  125.0,  160.0,
+                                200.0, 250.0, 315.0,  400.0,  500.0,  630.0,  800.0,  1000.0, 1250.0, 1600.0,
+                                2000.0, 2500.0, 3150.0, 4000.0, 5000.0, 6300.0, 8000.0, 10000.0, 12500.0};
+static const float kEarA[29] = {2.347, 2.190, 2.050, 1.879, 1.724, 1.579, 1.512, 1.466, 1.426, 1.394,
+                                1.372, 1.344, 1.304, 1.256, 1.203, 1.135, 1.062, 1.000, 0.967, 0.943,
+                                0.932, 0.933, 0.937, 0.952, 0.974, 1.027, 1.135, 1.266, 1.501};
+static const float kEarB[29] = {0.00561,  0.00527,  0.00481,  0.00404,  0.00383, 0.00286, 0.00259, 0.00257,
+                                0.00256,  0.00255,  0.00254,  0.00248,  0.00229, 0.00201, 0.00162, 0.00111,
+                                0.00052,  0.00000,  -0.00039, -0.00067, -0.00092, -0.00105, -0.00104,
+                                -0.00088, -0.00055, 0.00000,  0.00089,  0.00211, 0.00488};
+static const float kEarT[29] = {74.3, 65.0, 56.3, 48.4, 41.7, 35.5, 29.8, 25.1, 20.7, 16.8, 13.8, 11.2, 8.9, 7.2, 6.0,
+                                5.0,  4.4,  4.2,  3.7,  2.6,  1.0,  -1.2, -3.6, -3.9, -1.1, 6.6,  15.3, 16.4, 11.6};
+
+static float lerp_tab(const float *tab, int hi, float frac) { return tab[hi - 1] + frac * (tab[hi] - tab[hi - 1]); }
+
+static float phons_at(float hz)
+{
+    int hi = 0;
+    float frac, a, b, t;
+    while (kEarF[hi] < hz) hi++;
+    frac = (hz - kEarF[hi - 1]) / (kEarF[hi] - kEarF[hi - 1]);
+    a = lerp_tab(kEarA, hi, frac);
+    b = lerp_tab(kEarB, hi, frac);
+    t = lerp_tab(kEarT, hi, frac);
+    return (float)(4.2 + a * (60.0 - t) / (1.0 + b * (60.0 - t)));
+}
+
+void sea_build_gt_tables(sea_gt_tables *t)
+{
+    const double kPiHW = 3.1415926535897932384626433832795; /* HuWang.h:7 */
+    float erbLo = (float)(21.4 * log10(50 * 0.00437 + 1.0));
+    float erbHi = (float)(21.4 * log10(8000 * 0.00437 + 1.0));
+    float erbStep = (erbHi - erbLo) / (SEA_GT_NCHAN - 1);
+    float dt = 1 / (float)16000;
+    float twoPiT = (float)(2 * kPiHW * dt);
+    int c, n;
+    memset(t, 0, sizeof *t);
+    for (c = 0; c < SEA_GT_NCHAN; c++) {
+        float cf = (float)((pow(10, (erbLo + c * erbStep) / 21.4) - 1) / 0.00437);
+        float bw = (float)(24.7 * (cf * 0.00437 + 1.0) * 1.019);
+        float phon = (float)(phons_at(cf) - 60.0);
+        float ear = (float)pow(10, (double)(phon / 20));
+        float z = expf(-twoPiT * bw);
+        t->cf[c] = cf;
+        t->bw[c] = bw;
+        t->midEar[c] = ear;
+        t->gain[c] = (float)(ear * pow((double)(twoPiT * bw), 4.0) / 3.0);
+        t->f1[c] = cosf(cf * twoPiT) * z;
+        t->f2[c] = sinf(cf * twoPiT) * z;
+    }
+    for (n = 0; n < 160; n++) {
+        t->olaUp[n] = 0.5 * (1.0 + cos(n * kPiHW / (160) + kPiHW));
+        t->olaDown[n] = 0.5 * (1.0 + cos(n * kPiHW / (160)));
+    }
+}

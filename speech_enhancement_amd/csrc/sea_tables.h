@@ -1,0 +1,84 @@
+/*
+ * sea_tables.h -- constant tables of the MI355X noise-suppression engine, laid out lane-major
+ * (one column per wavefront lane) so a kernel loads its per-lane constants with one coalesced
+ * read each at start-up and then keeps them in VGPRs for the whole utterance.
+ *
+ * Built on the host by sea_tables.c (plain C, gcc -O2 -ffp-contract=off: the float/double
+ * promotions of the reference's init code are reproduced exactly; citations there).
+ */
+#ifndef SEA_TABLES_H
+#define SEA_TABLES_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    SEA_LANES = 64,
+    SEA_HOP = 80,          /* NS_FRAME_SHIFT      etsi/cpp/NoiseSup.h:52 */
+    SEA_WIN = 200,         /* NS_FRAME_LENGTH     etsi/cpp/NoiseSup.h:54 */
+    SEA_NFFT = 256,        /* NS_FFT_LENGTH       etsi/cpp/NoiseSup.h:43 */
+    SEA_NSPEC = 65,        /* NS_SPEC_ORDER       etsi/cpp/NoiseSup.h:41 */
+    SEA_NMEL = 25,         /* WF_MEL_ORDER        etsi/cpp/MelProcExports.h:18 */
+    SEA_NTAP = 17,         /* NS_FILTER_LENGTH    etsi/cpp/NoiseSup.h:28 */
+    SEA_MEL_TAPS = 10,     /* widest of the 25 Wiener mel bands (asserted at build) */
+    SEA_FFT_LSTAGES = 6,   /* split-radix levels n2 = 8..256 that go through LDS */
+    SEA_CC_NCHAN = 23,     /* CC_NUM_CHANNELS_WI8 etsi/cpp/CompCeps.c:37 */
+    SEA_CC_TAPS = 22,      /* widest of the 23 cepstral mel triangles (asserted at build) */
+    SEA_CC_NCEP = 14,      /* c1..c12, c0, logE   etsi/cpp/CompCeps.c:539-543 */
+    SEA_GT_NCHAN = 64      /* NUMBER_CHANNEL      resyth_64sub_ori/cpp/HuWang.h:13 */
+};
+
+/* FFT work-item kinds for one split-radix level (etsi/cpp/rfft.c:99-178) */
+enum { SEA_BF_NONE = 0, SEA_BF_PLAIN = 1, SEA_BF_PI4 = 2, SEA_BF_TWIDDLE = 3 };
+
+typedef struct {
+    /* rfft.c schedule, shared by NoiseSup and CompCeps.  Lane l owns the four bit-reversed
+     * positions 4r..4r+3, r = bitrev6(l), which receive input elements l, l+128, l+64, l+192. */
+    unsigned fftFlags[SEA_LANES];                 /* bit0: length-2 bf on (4r,4r+1); bit1: on
+                                                     (4r+2,4r+3); bit2: n2=4 plain bf on group */
+    unsigned fftItem[SEA_FFT_LSTAGES][SEA_LANES]; /* kind<<16 | b<<8 | a  (a=i1, b=i5) */
+    float fftTw[SEA_FFT_LSTAGES][4][SEA_LANES];   /* cc1, ss1, cc3, ss3 of twiddle items */
+} sea_fft_tables;
+
+typedef struct {
+    sea_fft_tables fft;
+    float win[4][SEA_LANES];                      /* Hanning(200)[l+64k], 0 beyond 199 */
+    int melStart[SEA_LANES], melLen[SEA_LANES];   /* lanes 0..24 */
+    float melW[SEA_MEL_TAPS][SEA_LANES];
+    float idct[SEA_NMEL][SEA_LANES];              /* idct[f][t], lanes t = 0..8 */
+    float irWin[SEA_LANES];                       /* lanes j = 0..8: Hanning(17)[8+j] */
+    float eps;                                    /* NS_EPS = (float)exp(-10.0) */
+    float pad[15];
+} sea_ns_tables;
+
+typedef struct {
+    sea_fft_tables fft;
+    float win[4][SEA_LANES];                      /* symmetric Hamming(200)[l+64k], 0 beyond */
+    int melStart[SEA_LANES], melLen[SEA_LANES];   /* lanes 0..22 */
+    float melW[SEA_CC_TAPS][SEA_LANES];
+    float dct[SEA_CC_NCHAN][SEA_LANES];           /* dct[j][i-1], lanes i-1 = 0..11 */
+    float floorFB, floorE;                        /* (float)exp(-10.0), (float)exp(-50.0) */
+    float pad[14];
+} sea_cc_tables;
+
+typedef struct {
+    float gain[SEA_GT_NCHAN], f1[SEA_GT_NCHAN], f2[SEA_GT_NCHAN], midEar[SEA_GT_NCHAN];
+    float cf[SEA_GT_NCHAN], bw[SEA_GT_NCHAN];
+    double olaUp[160], olaDown[160];              /* 0.5(1+cos(n pi/160 + pi)), 0.5(1+cos(n pi/160)) */
+} sea_gt_tables;
+
+void sea_build_ns_tables(sea_ns_tables *t);
+void sea_build_cc_tables(sea_cc_tables *t);
+void sea_build_gt_tables(sea_gt_tables *t);
+
+/* plain tables for host-side checks (tests compare them with the oracle's) */
+void sea_ns_plain_tables(float *sigWindow200, float *irWindow17, float *idct25x25, int *melStart25,
+                         int *melLen25, float *melData /* 25*16 */);
+void sea_cc_plain_tables(float *hamming100, float *dct12x23, int *melStart23, int *melLen23,
+                         float *melData /* 23*32 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
