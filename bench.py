@@ -156,12 +156,9 @@ def main():
     dt = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in events]
 
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
-
-    total_frames = frames_per_step * args.steps * world
+    # whole-job aggregate: frames summed over ranks, time = max over ranks (no data-path collective)
+    from speech_enhancement_amd.shard import reduce_job
+    total_frames, dt_max = reduce_job(frames_per_step * args.steps, dt, dist if world > 1 else None, device)
     value = total_frames / dt_max
 
     result = None

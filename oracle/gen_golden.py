@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""oracle/gen_golden.py -- TEST INFRASTRUCTURE ONLY.
+
+Generates the committed golden vectors under tests/golden/ by running THE REFERENCE ITSELF
+(oracle/_ref/libetsi_ref.so = /root/reference/etsi/cpp/*.c compiled in place by oracle/Makefile)
+on small seeded inputs.  Run in the build container (where /root/reference exists):
+
+    make -C oracle ref && python oracle/gen_golden.py
+
+Files written (inputs and expected outputs only -- data, no reference source):
+  tests/golden/ns_golden.npz        6 short utterances through etsi_denoise + the explicit
+                                    NoiseSup/CompCeps driver: int16 out, float stream, cepstra,
+                                    per-frame recursive state (scalars + 4 spectra)
+  tests/golden/rfft_golden.npz      32 frames of 256 floats and their rfft
+  tests/golden/compceps_golden.npz  16 stand-alone DoCompCeps frames (201 floats -> 14)
+  tests/golden/tables_golden.npz    every constant table of NoiseSup and CompCeps
+  tests/golden/resynth_kat.json     the resynth known answer RECORDED IN SURVEY.md 8(c) (the
+                                    resynth reference cannot be built here: no asdk Wave.h)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+from speech_enhancement_amd import corpus  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def golden_utterances():
+    utts = {
+        "plain_1s": corpus.synth_utterance(1, 16000),
+        "leading_zeros": corpus.synth_utterance(5, 8000),                 # first 400 samples are 0
+        "ragged": corpus.synth_utterance(2, 4000 + 37),                   # L % 80 != 0
+        "loud": np.clip(corpus.synth_utterance(6, 4800).astype(np.int32) * 6, -32768, 32767).astype(np.int16),
+        "gap": np.concatenate([np.zeros(640, np.int16), corpus.synth_utterance(7, 3200),
+                               np.zeros(1600, np.int16), corpus.synth_utterance(8, 2400)]),
+        "kat_head": O.kat_ns_signal(32000),                               # SURVEY 8(c) signal, first 4 s
+    }
+    return utts
+
+
+def main():
+    ref = O.Reference()
+    os.makedirs(GOLD, exist_ok=True)
+
+    pack = {}
+    for name, x in golden_utterances().items():
+        tr = ref.ns_trace(x, want_state=True)
+        den = ref.etsi_denoise(x, fill=-7777)
+        assert np.array_equal(den[: len(x) // 80 * 80], tr["out_i16"][: len(x) // 80 * 80])
+        pack[f"{name}/in"] = x
+        pack[f"{name}/etsi_denoise"] = den
+        pack[f"{name}/den_f32"] = tr["den_f32"]
+        pack[f"{name}/ceps"] = tr["ceps"]
+        pack[f"{name}/scal"] = tr["scal"]
+        pack[f"{name}/spec"] = tr["spec"].astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "ns_golden.npz"), **pack)
+
+    rng = np.random.default_rng(20251004)
+    frames = (rng.standard_normal((32, 256)) * rng.uniform(0.01, 20000.0, (32, 1))).astype(np.float32)
+    frames[0] = 0.0
+    frames[1] = 0.0
+    frames[1, 1] = 1.0
+    frames[2] = 1.0
+    np.savez_compressed(os.path.join(GOLD, "rfft_golden.npz"), frames=frames,
+                        rfft=np.stack([ref.rfft(f) for f in frames]))
+
+    cc_in = (rng.standard_normal((16, 201)) * rng.uniform(0.001, 8000.0, (16, 1))).astype(np.float32)
+    cc_in[0] = 0.0                      # both floors
+    cc_in[1] = 1e-6                     # mel floor only
+    np.savez_compressed(os.path.join(GOLD, "compceps_golden.npz"), data201=cc_in,
+                        coef=np.stack([ref.compceps_frame(d) for d in cc_in]))
+
+    t, c = ref.ns_tables(), ref.cc_tables()
+    np.savez_compressed(os.path.join(GOLD, "tables_golden.npz"),
+                        **{f"ns_{k}": v for k, v in t.items()}, **{f"cc_{k}": v for k, v in c.items()})
+
+    with open(os.path.join(GOLD, "resynth_kat.json"), "w") as f:
+        json.dump({
+            "source": "SURVEY.md 8(c): output of resyth_64sub_ori resynth() (g++ -O2) recorded by the survey",
+            "L": 48000, "seed": 1, "binary": False,
+            "out_8000_8009": [88, 528, 249, 1331, 1271, 1638, 2190, 1682, 1642, 2182],
+            "weighted_checksum": -2456454,
+            "ns_kat": {"L": 160000, "seed": 12345, "first_nonzero": 320,
+                       "out_320_335": [6, 27, 59, 76, 86, 82, 56, 67, 28, 7, -31, -52, -59, -78, -60, -84],
+                       "weighted_checksum": 91888,
+                       "ceps_frame0_first_32000": [-17.5454, 3.3785, -4.3244, -12.1480, -17.5113, -12.8107,
+                                                   -0.8582, 3.3935, 7.3065, 7.7821, 4.6556, -0.5107, 261.3745,
+                                                   13.6384]},
+        }, f, indent=1)
+    for fn in sorted(os.listdir(GOLD)):
+        print(fn, os.path.getsize(os.path.join(GOLD, fn)))
+
+
+if __name__ == "__main__":
+    main()

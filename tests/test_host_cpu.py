@@ -1,0 +1,178 @@
+"""CPU tests of the host side: the C ABI exports what include/sea_mi355x.h declares, host tables equal
+the oracle's, the product fails loudly without a GPU (no CPU fallback), batch packing, the
+synthetic corpus, and the multi-process sharding (gloo, world_size 2)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sea_mi355x.h")
+
+
+def _declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", text)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def _have_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_header_declares_the_reference_entry_points():
+    names = _declared_functions()
+    for must in ("etsi_denoise", "etsi_denoise_synchronization", "etsi_denoise_16k",
+                 "etsi_denoise_16k_synchronization", "rfft", "sea_ns_stream_alloc", "sea_ns_stream_init",
+                 "sea_ns_stream_push", "sea_ns_stream_delete", "sea_compceps_frame", "sea_resynth64",
+                 "sea_gammatone_filter", "sea_ns_denoise_batch", "sea_compceps_batch", "sea_resynth64_batch"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import _lib
+    assert os.path.exists(sea.LIB_PATH), "build with make -C speech_enhancement_amd/csrc"
+    lib = ctypes.CDLL(sea.LIB_PATH)
+    declared = _declared_functions()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/sea_mi355x.h but not exported"
+    assert set(declared) == set(_lib.PROTOTYPES), set(declared) ^ set(_lib.PROTOTYPES)
+    assert b"gfx950" in sea.load().sea_version()
+
+
+def test_library_contains_gfx950_code_object():
+    import speech_enhancement_amd as sea
+    blob = open(sea.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"ns_denoise_kernel" in blob
+
+
+def test_host_tables_match_oracle(oracle):
+    """sea_tables_host needs no GPU: the product's own table builder (csrc/sea_tables.c) against the
+    oracle's, entry by entry, bit for bit."""
+    import speech_enhancement_amd as sea
+    t = sea.tables()
+    a, c = oracle.ns_tables(), oracle.cc_tables()
+    for k in a:
+        assert np.array_equal(t[k].view(np.uint32), a[k].view(np.uint32)), k
+    for mine, theirs in (("hamming", "hamming"), ("dct", "dct"), ("ccStart", "melStart"), ("ccLen", "melLen"),
+                         ("ccData", "melData")):
+        assert np.array_equal(t[mine].view(np.uint32), c[theirs].view(np.uint32)), mine
+    cf, bw, me = oracle.resynth_channels()
+    assert np.array_equal(t["cf"], cf) and np.array_equal(t["bw"], bw) and np.array_equal(t["midEar"], me)
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a box without a GPU the product must fail loudly, never compute on the CPU."""
+    if _have_gpu():
+        pytest.skip("GPU present")
+    import speech_enhancement_amd as sea
+    x = np.ones(800, np.int16)
+    with pytest.raises(sea.SeaError):
+        sea.etsi_denoise(x)
+    with pytest.raises(sea.SeaError):
+        sea.DoCompCeps(np.zeros(201, np.float32))
+    with pytest.raises(sea.SeaError):
+        sea.resynth(np.zeros(640, np.int16), np.zeros((3, 64), np.float32))
+    lib = sea.load()
+    assert lib.sea_init(-1) != 0 and lib.sea_last_error()
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under speech_enhancement_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "speech_enhancement_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".c", ".h", ".hip", ".cpp")) or fn == "Makefile":
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "libsea_oracle" not in text and "from oracle" not in text and "import oracle" not in text, fn
+                assert not re.search(r"\b(ora|ref)_[a-z0-9_]+\s*\(", text), fn
+
+
+def test_packed_batch_layout():
+    import speech_enhancement_amd as sea
+    lengths = [1000, 0, 79, 4001, 8]
+    offs, total, order = sea.PackedBatch.layout(lengths)
+    assert list(offs) == [0, 1000, 1000, 1080, 5088] and total == 5096
+    assert all(o % 8 == 0 for o in offs)
+    assert list(order) == [3, 0, 2, 4, 1]                      # longest first, stable
+    b = sea.PackedBatch.from_arrays([np.arange(n, dtype=np.int16) for n in lengths], device="cpu")
+    assert b.n_utt == 5 and b.n_frames == 12 + 0 + 0 + 50 + 0
+    parts = b.split(b.data)
+    assert [len(p) for p in parts] == lengths and np.array_equal(parts[3], np.arange(4001, dtype=np.int16))
+    assert [len(p) for p in b.split(b.data, full_frames_only=True)] == [960, 0, 0, 4000, 0]
+
+
+def test_corpus_is_deterministic_and_matches_scalar_lcg():
+    from speech_enhancement_amd import corpus
+    s, ref = 12345, []
+    for _ in range(50):
+        s = (s * 1664525 + 1013904223) & 0xFFFFFFFF
+        ref.append(s)
+    assert list(corpus.lcg_stream(12345, 50)) == ref
+    a, b = corpus.synth_utterance(5), corpus.synth_utterance(5)
+    assert np.array_equal(a, b) and a.dtype == np.int16
+    assert len(a) == corpus.utterance_length(5) and len(a) % 160 == 0
+    assert not np.any(a[:400]) and np.any(a[400:480])           # every 5th utterance starts silent
+    lens = [corpus.utterance_length(u) for u in range(2000)]
+    assert 32000 <= min(lens) and max(lens) <= 96000 and abs(np.mean(lens) - 64000) < 2000
+    m = corpus.synth_mask(3, 4800)
+    assert m.shape == ((4800 - 320) // 160 + 1, 64) and 0 <= m.min() and m.max() < 1
+
+
+def test_lpt_and_block_sharding():
+    from speech_enhancement_amd import corpus
+    from speech_enhancement_amd.shard import block_shard, lpt_shards
+    lengths = [corpus.utterance_length(u) for u in range(1000)]
+    shards = lpt_shards(lengths, 8)
+    allidx = np.concatenate(shards)
+    assert sorted(allidx) == list(range(1000))
+    loads = [sum(lengths[i] for i in s) for s in shards]
+    assert (max(loads) - min(loads)) / np.mean(loads) < 0.01
+    covered = [i for r in range(8) for i in block_shard(1003, 8, r)]
+    assert covered == list(range(1003))
+
+
+_GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from speech_enhancement_amd import corpus
+from speech_enhancement_amd.shard import lpt_shards, block_shard, reduce_job
+dist.init_process_group("gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+lengths = [corpus.utterance_length(u) for u in range(64)]
+mine = lpt_shards(lengths, world)[rank]
+frames = int(sum(lengths[i] // 80 for i in mine))
+gathered = [None] * world
+dist.all_gather_object(gathered, [int(i) for i in mine])
+flat = sorted(i for g in gathered for i in g)
+assert flat == list(range(64)), flat
+total, tmax = reduce_job(frames, 1.0 + rank, dist, torch.device("cpu"))
+assert total == sum(l // 80 for l in lengths) and tmax == float(world)
+blk = list(block_shard(64, world, rank))
+dist.all_gather_object(gathered, blk)
+assert sorted(i for g in gathered for i in g) == list(range(64))
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharding_world_size_2_gloo(tmp_path):
+    """The N>1 path without GPUs: two gloo ranks shard a corpus, cover it exactly once, and reduce
+    the job totals the way bench.py does (frames: sum, seconds: max)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
