@@ -106,6 +106,9 @@ int sea_compceps_frame(const float *Data, float *Coef14);
 
 /* resynth(): in/out L samples, mask [F][64] with F=(L-320)/160+1 (host pointers) */
 int sea_resynth64(const short *in, long L, const float *mask, int F, int binary, short *out);
+/* many utterances at once from host memory (masks[u] is [F_u][64]); one pair of launches */
+int sea_resynth_utterances(const short *const *in, const long *lengths, const float *const *masks, int binary,
+                           short *const *out, int n_utt);
 /* gammaToneFilter(input, output, fChan, sigLength) for channel `chan` of the 64-band bank */
 int sea_gammatone_filter(const float *input, float *output, int chan, long sigLength);
 

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "sea_denoise_utterances": (_i, [_vp, _vp, _vp, _i]),
     "sea_compceps_frame": (_i, [_vp, _vp]),
     "sea_resynth64": (_i, [_vp, _l, _vp, _i, _i, _vp]),
+    "sea_resynth_utterances": (_i, [_vp, _vp, _vp, _i, _vp, _i]),
     "sea_gammatone_filter": (_i, [_vp, _vp, _i, _l]),
     "sea_ns_stream_alloc": (_vp, []),
     "sea_ns_stream_init": (None, [_vp]),

@@ -348,6 +348,48 @@ int sea_resynth64(const short *in, long L, const float *mask, int F, int binary,
     return 0;
 }
 
+int sea_resynth_utterances(const short *const *in, const long *lengths, const float *const *masks, int binary,
+                           short *const *out, int n_utt)
+{
+    if (n_utt <= 0) return 0;
+    std::vector<long long> offs(n_utt), lens(n_utt), moffs(n_utt);
+    long long total = 0, rows = 0;
+    for (int u = 0; u < n_utt; ++u) {
+        if (lengths[u] < 320) return fail("resynth: utterance %d has %ld samples (< one 320-sample window)", u, lengths[u]);
+        offs[u] = total;
+        lens[u] = lengths[u];
+        moffs[u] = rows;
+        total += align8(lengths[u]);
+        rows += (lengths[u] - 320) / 160 + 1;
+    }
+    std::vector<short> pack((size_t)total, 0);
+    std::vector<float> mpack((size_t)rows * 64);
+    for (int u = 0; u < n_utt; ++u) {
+        memcpy(&pack[(size_t)offs[u]], in[u], (size_t)lens[u] * sizeof(short));
+        memcpy(&mpack[(size_t)moffs[u] * 64], masks[u], (size_t)((lens[u] - 320) / 160 + 1) * 64 * sizeof(float));
+    }
+    DevBuf<short> din, dout;
+    DevBuf<float> dmask, dinter;
+    DevBuf<long long> dmeta;
+    HIP_TRY(din.alloc((size_t)total));
+    HIP_TRY(dout.alloc((size_t)total));
+    HIP_TRY(dmask.alloc(mpack.size()));
+    HIP_TRY(dinter.alloc((size_t)total * 64));
+    HIP_TRY(dmeta.alloc(3 * (size_t)n_utt));
+    HIP_TRY(hipMemcpy(din.p, pack.data(), (size_t)total * sizeof(short), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dmask.p, mpack.data(), mpack.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dmeta.p, offs.data(), n_utt * sizeof(long long), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dmeta.p + n_utt, lens.data(), n_utt * sizeof(long long), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dmeta.p + 2 * n_utt, moffs.data(), n_utt * sizeof(long long), hipMemcpyHostToDevice));
+    if (sea_resynth64_batch(din.p, dout.p, dmeta.p, dmeta.p + n_utt, dmask.p, dmeta.p + 2 * n_utt, dinter.p, nullptr,
+                            n_utt, binary, nullptr))
+        return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(pack.data(), dout.p, (size_t)total * sizeof(short), hipMemcpyDeviceToHost));
+    for (int u = 0; u < n_utt; ++u) memcpy(out[u], &pack[(size_t)offs[u]], (size_t)lens[u] * sizeof(short));
+    return 0;
+}
+
 int sea_gammatone_filter(const float *input, float *output, int chan, long sigLength)
 {
     if (chan < 0 || chan >= 64) return fail("gammatone: channel %d out of range", chan);

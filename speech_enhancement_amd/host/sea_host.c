@@ -1,0 +1,152 @@
+/* sea_host.c -- see sea_host.h */
+#include "sea_host.h"
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static void chop_last(char *s)
+{ /* the reference's chop(): drops the last character whatever it is */
+    size_t n = strlen(s);
+    if (n) s[n - 1] = '\0';
+}
+
+static int cfg_line(FILE *fp, char *value, int *ivalue)
+{
+    char line[2 * SEA_FILE_LEN], key[SEA_FILE_LEN];
+    if (!fgets(line, sizeof line, fp)) return 1;
+    chop_last(line);
+    if (value) {
+        value[0] = '\0';
+        sscanf(line, "%1023s %1023s", key, value);
+    } else
+        sscanf(line, "%1023s %d", key, ivalue);
+    return 0;
+}
+
+int sea_read_cfg(const char *path, int has_numMix, sea_cfg *c)
+{
+    FILE *fp = fopen(path, "r");
+    int bad = 0;
+    memset(c, 0, sizeof *c);
+    if (!fp) {
+        printf("Open %s file error!\n", path);
+        return 1;
+    }
+    bad |= cfg_line(fp, c->purewavDictionary, NULL);
+    bad |= cfg_line(fp, c->purewavlist, NULL);
+    if (has_numMix) bad |= cfg_line(fp, NULL, &c->numMix);
+    bad |= cfg_line(fp, c->outputDictionary, NULL);
+    bad |= cfg_line(fp, c->save_noisy_dir, NULL);
+    bad |= cfg_line(fp, c->save_noisy_ebm_dir, NULL);
+    bad |= cfg_line(fp, c->save_noisy_sirm_dir, NULL);
+    bad |= cfg_line(fp, c->save_resynth_e_dir, NULL);
+    bad |= cfg_line(fp, c->save_resynth_i_dir, NULL);
+    bad |= cfg_line(fp, c->Log, NULL);
+    fclose(fp);
+    return bad;
+}
+
+int sea_read_list(const char *path, char ***ids)
+{
+    FILE *fp = fopen(path, "r");
+    char line[SEA_FILE_LEN];
+    int n = 0, cap = 0;
+    *ids = NULL;
+    if (!fp) return -1;
+    while (fgets(line, sizeof line, fp)) {
+        chop_last(line);
+        if (n == cap) {
+            cap = cap ? 2 * cap : 64;
+            *ids = (char **)realloc(*ids, cap * sizeof(char *));
+        }
+        (*ids)[n++] = strdup(line);
+    }
+    fclose(fp);
+    return n;
+}
+
+void sea_free_list(char **ids, int n)
+{
+    int i;
+    for (i = 0; i < n; i++) free(ids[i]);
+    free(ids);
+}
+
+static uint32_t rd32(const unsigned char *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+static uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+int sea_wav_read(const char *path, short **data, long *n, int *fs)
+{
+    FILE *fp = fopen(path, "rb");
+    unsigned char h[12], ck[8], fmt[16];
+    int channels = 0, bits = 0, format = 0, have_fmt = 0;
+    *data = NULL;
+    *n = 0;
+    if (!fp) return 1;
+    if (fread(h, 1, 12, fp) != 12 || memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) goto bad;
+    while (fread(ck, 1, 8, fp) == 8) {
+        uint32_t size = rd32(ck + 4);
+        if (!memcmp(ck, "fmt ", 4)) {
+            if (size < 16 || fread(fmt, 1, 16, fp) != 16) goto bad;
+            format = rd16(fmt);
+            channels = rd16(fmt + 2);
+            *fs = (int)rd32(fmt + 4);
+            bits = rd16(fmt + 14);
+            have_fmt = 1;
+            fseek(fp, (long)(size - 16 + (size & 1)), SEEK_CUR);
+        } else if (!memcmp(ck, "data", 4)) {
+            long frames, i;
+            unsigned char *raw;
+            if (!have_fmt || format != 1 || bits != 16 || channels < 1) goto bad;
+            frames = (long)(size / (2u * (unsigned)channels));
+            raw = (unsigned char *)malloc(size ? size : 1);
+            frames = (long)(fread(raw, 2u * (unsigned)channels, (size_t)frames, fp));
+            *data = (short *)malloc((size_t)(frames ? frames : 1) * sizeof(short));
+            for (i = 0; i < frames; i++) (*data)[i] = (short)rd16(raw + (size_t)i * 2u * (unsigned)channels);
+            free(raw);
+            *n = frames;
+            fclose(fp);
+            return 0;
+        } else
+            fseek(fp, (long)(size + (size & 1)), SEEK_CUR);
+    }
+bad:
+    fclose(fp);
+    return 2;
+}
+
+static void wr32(unsigned char *p, uint32_t v) { p[0] = v & 255; p[1] = (v >> 8) & 255; p[2] = (v >> 16) & 255; p[3] = (v >> 24) & 255; }
+static void wr16(unsigned char *p, uint16_t v) { p[0] = v & 255; p[1] = (v >> 8) & 255; }
+
+int sea_wav_write(const char *path, const short *data, long n, int fs)
+{
+    FILE *fp = fopen(path, "wb");
+    unsigned char h[44];
+    long i;
+    if (!fp) {
+        fprintf(stderr, "Cannot write in the file %s\n", path);
+        return 1;
+    }
+    memcpy(h, "RIFF", 4);
+    wr32(h + 4, (uint32_t)(36 + 2 * n));
+    memcpy(h + 8, "WAVEfmt ", 8);
+    wr32(h + 16, 16);
+    wr16(h + 20, 1);
+    wr16(h + 22, 1);
+    wr32(h + 24, (uint32_t)fs);
+    wr32(h + 28, (uint32_t)fs * 2u);
+    wr16(h + 32, 2);
+    wr16(h + 34, 16);
+    memcpy(h + 36, "data", 4);
+    wr32(h + 40, (uint32_t)(2 * n));
+    fwrite(h, 1, 44, fp);
+    for (i = 0; i < n; i++) {
+        unsigned char s[2];
+        wr16(s, (uint16_t)data[i]);
+        fwrite(s, 1, 2, fp);
+    }
+    fclose(fp);
+    return 0;
+}
