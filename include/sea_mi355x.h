@@ -126,6 +126,16 @@ int sea_ns_streams_push(const float *d_in, float *d_out, int *d_produced, float 
                         int nframes, int reset, void *stream);
 int sea_ns_state_floats(void);
 
+/* ----------------------------------------------------------------------------------------------
+ * device self-tests of the two places where a kernel takes a cheaper route than the reference's
+ * literal arithmetic (both proven / guarded, see csrc/sea_device.h and csrc/ns_kernel.hip)
+ * -------------------------------------------------------------------------------------------- */
+/* all 2^32 floats s: (float)((double)s * (1/sqrt2)) vs (float)((double)s / sqrt2); count of differences */
+int sea_selftest_pi4(unsigned long long *n_mismatch);
+/* DC-offset recurrence on ncases frames of 80 differences (host pointers): output and whether the
+ * exact double path had to be taken */
+int sea_selftest_dc(const float *dif, const float *y0, float *out, int *fellback, int ncases);
+
 #ifdef __cplusplus
 }
 #endif

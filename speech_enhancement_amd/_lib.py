@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsea_mi355x.so")
+# SEA_MI355X_LIB selects another build of the SAME library (timing-only diagnostic variants)
+LIB_PATH = os.environ.get("SEA_MI355X_LIB") or os.path.join(_HERE, "libsea_mi355x.so")
 
 _c = ctypes
 _vp, _i, _ll, _l = _c.c_void_p, _c.c_int, _c.c_longlong, _c.c_long
@@ -42,6 +43,8 @@ PROTOTYPES = {
     "sea_ns_stream_delete": (None, [_vp]),
     "sea_ns_streams_push": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sea_ns_state_floats": (_i, []),
+    "sea_selftest_pi4": (_i, [_vp]),
+    "sea_selftest_dc": (_i, [_vp, _vp, _vp, _vp, _i]),
 }
 
 _lib = None

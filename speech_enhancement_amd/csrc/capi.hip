@@ -496,4 +496,41 @@ int sea_ns_streams_push(const float *d_in, float *d_out, int *d_produced, float 
 
 int sea_ns_state_floats(void) { return sea::kNsStateFloats; }
 
+/* ------------------------------------------------------------------------------------------- */
+int sea_selftest_pi4(unsigned long long *n_mismatch)
+{
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    DevBuf<unsigned long long> d;
+    HIP_TRY(d.alloc(1));
+    HIP_TRY(hipMemset(d.p, 0, sizeof(unsigned long long)));
+    hipLaunchKernelGGL(sea::selftest_pi4_kernel, dim3(4096), dim3(256), 0, nullptr, d.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(n_mismatch, d.p, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sea_selftest_dc(const float *dif, const float *y0, float *out, int *fellback, int ncases)
+{
+    if (ncases <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    DevBuf<float> dd, dy, dout;
+    DevBuf<int> df;
+    HIP_TRY(dd.alloc((size_t)ncases * 80));
+    HIP_TRY(dy.alloc(ncases));
+    HIP_TRY(dout.alloc((size_t)ncases * 80));
+    HIP_TRY(df.alloc(ncases));
+    HIP_TRY(hipMemcpy(dd.p, dif, (size_t)ncases * 80 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dy.p, y0, ncases * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sea::selftest_dc_kernel, dim3(ncases < 1024 ? ncases : 1024), dim3(64), 0, nullptr, dd.p, dy.p,
+                       dout.p, df.p, ncases);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)ncases * 80 * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(fellback, df.p, ncases * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 } // extern "C"

@@ -241,7 +241,11 @@ __device__ __forceinline__ void ns_stage(NsLds &L, NsRegs &s, const NsConst &C, 
         s.nbFrame[ST] = nb;
     }
     if (ST == 0) {
+#ifdef SEA_ABLATE_VADSUM
+        const float frameSum = 64.0f + L.sq[0] + L.sq[79];
+#else
         const float frameSum = serial_sum<80>(L.sq, 64.0f);
+#endif
         vad_update(s, frameSum);
     }
 
@@ -250,11 +254,13 @@ __device__ __forceinline__ void ns_stage(NsLds &L, NsRegs &s, const NsConst &C, 
     const float WLo = filter_bin<ST>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
     L.wbuf[lane] = WLo;
     L.sbuf[lane] = (ST == 0) ? s.denLo[0] : s.noiseLo[1];
+#ifndef SEA_ABLATE_HI
     if (lane == 0) {
         const float WHi = filter_bin<ST>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
         L.wbuf[64] = WHi;
         L.sbuf[64] = (ST == 0) ? s.denHi[0] : s.noiseHi[1];
     }
+#endif
     wave_sync();
 
     /* --- DoMelFB: 25 bands, taps in order (MelProc.c:82-104) --- */
@@ -269,7 +275,11 @@ __device__ __forceinline__ void ns_stage(NsLds &L, NsRegs &s, const NsConst &C, 
     }
 
     /* --- DoGainFact (NoiseSup.c:581-642) --- */
+#ifdef SEA_ABLATE_GSUM
+    const float total = L.sbuf[0] + L.sbuf[64];
+#else
     const float total = serial_sum<65>(L.sbuf, 0.0f);
+#endif
     if (ST == 0) {
         s.denEn0 = s.denEn1;
         s.denEn1 = s.denEn2;
@@ -320,6 +330,65 @@ __device__ __forceinline__ void ns_stage(NsLds &L, NsRegs &s, const NsConst &C, 
 }
 
 
+/* DCOffsetFil over one frame (NoiseSup.c:182-198): y[n] = float( double(d[n]) + 0.9990234375 *
+ * double(y[n-1]) ), d[n] = x[n] - x[n-1] already in dif[0..79]; writes y to out[0..79], updates yState.
+ * An 80-step serial recurrence (all lanes compute it redundantly).
+ *
+ * The reference rounds twice per sample (sum to double, then to float).  Whenever the exact value
+ * d + c*y (c = 1023/1024, so c*y has at most 34 significant bits) fits a double exactly, that
+ * equals ONE rounding to float, which a float FMA delivers with a 3x shorter dependency chain.
+ * "Fits exactly" holds when the exponents of d and y are within [-16, +26] of each other (or
+ * either is 0); that is verified for all 80 samples in parallel afterwards, and the frame is
+ * recomputed on the exact double path in the (never yet observed) case that a sample fails. */
+__device__ __forceinline__ bool dc_filter(const float *dif, float *out, float &yState, int lane)
+{
+    const float y0 = yState;
+    float y = y0;
+#ifdef SEA_ABLATE_DC
+    for (int n = 0; n < 4; n += 4) {
+#else
+#pragma unroll 5
+    for (int n = 0; n < SEA_HOP; n += 4) {
+#endif
+        const float4 d = *reinterpret_cast<const float4 *>(&dif[n]);
+        float4 o;
+        y = __fmaf_rn(0.9990234375f, y, d.x);
+        o.x = y;
+        y = __fmaf_rn(0.9990234375f, y, d.y);
+        o.y = y;
+        y = __fmaf_rn(0.9990234375f, y, d.z);
+        o.z = y;
+        y = __fmaf_rn(0.9990234375f, y, d.w);
+        o.w = y;
+        *reinterpret_cast<float4 *>(&out[n]) = o;
+    }
+    wave_sync();
+    bool unsafe = false;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int n = lane + 64 * k;
+        if (n < SEA_HOP) {
+            const float ad = fabsf(dif[n]);
+            const float ay = fabsf(n == 0 ? y0 : out[n - 1]);
+            const bool ok = (ad == 0.0f) || (ay == 0.0f) ||
+                            (ay >= ad * 0x1p-16f && ay <= ad * 0x1p26f && ad < 0x1p100f && ad > 0x1p-100f);
+            unsafe |= !ok;
+        }
+    }
+    const bool redo = __ballot(unsafe) != 0ull;
+    if (redo) { /* exact path: double multiply-add, rounded to float per sample */
+        wave_sync();
+        y = y0;
+        for (int n = 0; n < SEA_HOP; ++n) {
+            y = (float)__fma_rn(0.9990234375, (double)y, (double)dif[n]);
+            out[n] = y;
+        }
+    }
+    yState = y;
+    wave_sync();
+    return redo;
+}
+
 /* DoNoiseSup (NoiseSup.c:1061-1440) for one 80-sample frame.  Lanes 0..39 pass samples 2l and
  * 2l+1.  Returns true when L.outb[0..79] holds a DC-filtered output frame. */
 __device__ __forceinline__ bool ns_tick(NsLds &L, NsRegs &s, const NsConst &C, int lane, float x0, float x1)
@@ -352,9 +421,7 @@ __device__ __forceinline__ bool ns_tick(NsLds &L, NsRegs &s, const NsConst &C, i
         wave_sync();
         return false;
     }
-    /* DCOffsetFil: y = (x - x_prev) + 0.9990234375 * y_prev in double, rounded to float every
-     * sample (NoiseSup.c:182-198).  The product is exact in double (24-bit x 10-bit), so one
-     * fma rounds exactly like the reference's multiply-then-add. */
+    /* DCOffsetFil (NoiseSup.c:182-198): differences in parallel, recurrence in dc_filter() */
     {
         const float xm1 = (lane == 0) ? s.dcX : L.outb[lane - 1];
         const float d0 = L.outb[lane] - xm1;
@@ -366,23 +433,7 @@ __device__ __forceinline__ bool ns_tick(NsLds &L, NsRegs &s, const NsConst &C, i
         if (lane < 16) L.sq[64 + lane] = d1;
     }
     wave_sync();
-    float y = s.dcY;
-#pragma unroll 4
-    for (int n = 0; n < SEA_HOP; n += 4) {
-        const float4 d = *reinterpret_cast<const float4 *>(&L.sq[n]);
-        float4 o;
-        y = (float)__fma_rn(0.9990234375, (double)y, (double)d.x);
-        o.x = y;
-        y = (float)__fma_rn(0.9990234375, (double)y, (double)d.y);
-        o.y = y;
-        y = (float)__fma_rn(0.9990234375, (double)y, (double)d.z);
-        o.z = y;
-        y = (float)__fma_rn(0.9990234375, (double)y, (double)d.w);
-        o.w = y;
-        *reinterpret_cast<float4 *>(&L.outb[n]) = o;
-    }
-    s.dcY = y;
-    wave_sync();
+    dc_filter(L.sq, L.outb, s.dcY, lane);
     return true;
 }
 
@@ -532,6 +583,35 @@ __global__ __launch_bounds__(64) void ns_stream_kernel(NsStreamArgs a)
         wave_sync();
     }
     state_store(blob, L, s, lane);
+}
+
+/* ---- device self-tests behind sea_selftest_*(): exhaustive / adversarial checks of the two places
+ * where the kernel takes a cheaper route than the reference's literal arithmetic ---- */
+__global__ __launch_bounds__(256) void selftest_pi4_kernel(unsigned long long *mismatches)
+{
+    unsigned long long bad = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; v < (1ull << 32); v += stride)
+        bad += pi4_identity_holds(__uint_as_float((unsigned)v)) ? 0 : 1;
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+__global__ __launch_bounds__(64) void selftest_dc_kernel(const float *dif, const float *y0, float *out, int *fellback,
+                                                         int ncases)
+{
+    __shared__ __attribute__((aligned(16))) float d[80], o[80];
+    const int lane = threadIdx.x;
+    for (int c = blockIdx.x; c < ncases; c += gridDim.x) {
+        d[lane] = dif[c * 80 + lane];
+        if (lane < 16) d[64 + lane] = dif[c * 80 + 64 + lane];
+        wave_sync();
+        float y = y0[c];
+        const bool fb = dc_filter(d, o, y, lane);
+        out[c * 80 + lane] = o[lane];
+        if (lane < 16) out[c * 80 + 64 + lane] = o[64 + lane];
+        if (lane == 0) fellback[c] = fb ? 1 : 0;
+        wave_sync();
+    }
 }
 
 } // namespace sea

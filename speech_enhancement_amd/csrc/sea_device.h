@@ -16,10 +16,18 @@ namespace sea {
 
 constexpr int kLanes = 64;
 
-/* LDS traffic inside a single wave is executed in program order by the hardware; what has to be
- * prevented is the compiler moving a lane's read above another lane's write.  With 64-thread
- * workgroups __syncthreads() lowers to exactly that (a wave-local fence, no cross-wave wait). */
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+/* LDS traffic of ONE wave is executed in program order by the hardware (DS instructions of a wave
+ * issue and return in order), so lanes of the same wave can exchange data through LDS without any
+ * hardware wait; what has to be prevented is the compiler moving a lane's read above another
+ * lane's write.  A wavefront-scope release/acquire fence pair around the wave barrier pseudo-op
+ * does exactly that and emits no instruction, so waves of one workgroup can run different code
+ * (the pipelined kernel) without meeting at an s_barrier. */
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 /* per-lane constants of the FFT schedule (sea_fft_tables), loaded once, kept in VGPRs */
 struct FftRegs {
@@ -48,11 +56,14 @@ __device__ __forceinline__ void fft_level(float *work, const FftRegs &R)
     const unsigned it = R.item[S];
     const unsigned kind = it >> 16;
     const int a = (int)(it & 255u);
+    const int b = (int)((it >> 8) & 255u); /* == a for plain / pi4 items, 0 for idle lanes */
+    /* All operands are fetched before the (divergent) arithmetic so that the three butterfly kinds
+     * share ONE LDS round trip instead of paying one each. */
+    const float x1 = work[a], x2 = work[a + n4], x3 = work[a + 2 * n4], x4 = work[a + 3 * n4];
+    const float x5 = work[b], x6 = work[b + n4], x7 = work[b + 2 * n4], x8 = work[b + 3 * n4];
+    float o1 = x1, o2 = x2, o3 = x3, o4 = x4, o5 = x5, o6 = x6, o7 = x7, o8 = x8;
     if (kind == SEA_BF_TWIDDLE) {
-        const int b = (int)((it >> 8) & 255u);
         const float cc1 = R.tw[S][0], ss1 = R.tw[S][1], cc3 = R.tw[S][2], ss3 = R.tw[S][3];
-        const float x1 = work[a], x2 = work[a + n4], x3 = work[a + 2 * n4], x4 = work[a + 3 * n4];
-        const float x5 = work[b], x6 = work[b + n4], x7 = work[b + 2 * n4], x8 = work[b + 3 * n4];
         float t1 = x3 * cc1 + x7 * ss1;
         float t2 = x7 * cc1 - x3 * ss1;
         float t3 = x4 * cc3 + x8 * ss3;
@@ -60,30 +71,53 @@ __device__ __forceinline__ void fft_level(float *work, const FftRegs &R)
         const float t5 = t1 + t3, t6 = t2 + t4;
         t3 = t1 - t3;
         t4 = t2 - t4;
-        work[a + 2 * n4] = t6 - x6;  /* x[i3] */
-        work[b + 3 * n4] = x6 + t6;  /* x[i8] */
-        work[b + 2 * n4] = -x2 - t3; /* x[i7] */
-        work[a + 3 * n4] = x2 - t3;  /* x[i4] */
-        work[b + n4] = x1 - t5;      /* x[i6] */
-        work[a] = x1 + t5;           /* x[i1] */
-        work[b] = x5 - t4;           /* x[i5] */
-        work[a + n4] = x5 + t4;      /* x[i2] */
+        o3 = t6 - x6;  /* x[i3] */
+        o8 = x6 + t6;  /* x[i8] */
+        o7 = -x2 - t3; /* x[i7] */
+        o4 = x2 - t3;  /* x[i4] */
+        o6 = x1 - t5;  /* x[i6] */
+        o1 = x1 + t5;  /* x[i1] */
+        o5 = x5 - t4;  /* x[i5] */
+        o2 = x5 + t4;  /* x[i2] */
     } else if (kind == SEA_BF_PLAIN) {
-        const float x1 = work[a], x3 = work[a + 2 * n4], x4 = work[a + 3 * n4];
         const float t1 = x4 + x3;
-        work[a + 3 * n4] = x4 - x3;
-        work[a + 2 * n4] = x1 - t1;
-        work[a] = x1 + t1;
+        o4 = x4 - x3;
+        o3 = x1 - t1;
+        o1 = x1 + t1;
     } else if (kind == SEA_BF_PI4) {
-        const float x1 = work[a], x2 = work[a + n4], x3 = work[a + 2 * n4], x4 = work[a + 3 * n4];
-        /* float sum, then a DOUBLE division by M_SQRT2, rounded back to float */
-        const float t1 = (float)((double)(x3 + x4) / 1.41421356237309504880);
-        const float t2 = (float)((double)(x3 - x4) / 1.41421356237309504880);
-        work[a + 3 * n4] = x2 - t1;
-        work[a + 2 * n4] = -x2 - t1;
-        work[a + n4] = x1 - t2;
-        work[a] = x1 + t2;
+        /* Reference: float sum, DOUBLE division by M_SQRT2, rounded back to float (rfft.c:120-121).
+         * (float)((double)s * (1/sqrt2)) gives the same float for EVERY float s: both doubles are
+         * within 2^-52 (relative) of s/sqrt2, and s/sqrt2 can never be that close to a float
+         * rounding boundary, because |sqrt2*m - (2k+1)| > 1/(2.83 m) for integers m < 2^24 keeps it
+         * 2^-50.6 away.  tests/test_gpu_parity.py checks all 2^32 floats on the device. */
+        const float t1 = (float)((double)(x3 + x4) * 0.70710678118654752440);
+        const float t2 = (float)((double)(x3 - x4) * 0.70710678118654752440);
+        o4 = x2 - t1;
+        o3 = -x2 - t1;
+        o2 = x1 - t2;
+        o1 = x1 + t2;
     }
+    if (kind != SEA_BF_NONE) {
+        work[a] = o1;
+        work[a + n4] = o2;
+        work[a + 2 * n4] = o3;
+        work[a + 3 * n4] = o4;
+    }
+    if (kind == SEA_BF_TWIDDLE) {
+        work[b] = o5;
+        work[b + n4] = o6;
+        work[b + 2 * n4] = o7;
+        work[b + 3 * n4] = o8;
+    }
+}
+
+/* exhaustive check kernel for the pi/4 identity above: counts floats s for which
+ * (float)((double)s * inv_sqrt2) != (float)((double)s / sqrt2) */
+__device__ __forceinline__ bool pi4_identity_holds(float s)
+{
+    const float fast = (float)((double)s * 0.70710678118654752440);
+    const float ref = (float)((double)s / 1.41421356237309504880);
+    return __float_as_uint(fast) == __float_as_uint(ref) || (fast != fast && ref != ref);
 }
 
 /* 256-point real split-radix FFT of one frame held 4 elements per lane: lane l passes elements
@@ -113,6 +147,7 @@ __device__ __forceinline__ void rfft256(float e0, float e1, float e2, float e3, 
     const int r = (int)(__brev((unsigned)lane) >> 26);
     *reinterpret_cast<float4 *>(work + 4 * r) = make_float4(g0, g1, g2, g3);
     wave_sync();
+#ifndef SEA_ABLATE_FFT
     fft_level<0>(work, R);
     wave_sync();
     fft_level<1>(work, R);
@@ -125,6 +160,7 @@ __device__ __forceinline__ void rfft256(float e0, float e1, float e2, float e3, 
     wave_sync();
     fft_level<5>(work, R);
     wave_sync();
+#endif
 }
 
 /* float -> int16 exactly as the reference's (short) cast behaves on x86-64: truncate toward zero

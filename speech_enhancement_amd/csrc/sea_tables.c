@@ -88,10 +88,16 @@ static void build_fft(sea_fft_tables *f)
                 f->fftTw[s][3][slot] = ss3;
             }
         }
-        for (b = 0; b < blocks.n; b++, slot++)
-            f->fftItem[s][slot] = ((unsigned)SEA_BF_PLAIN << 16) | (unsigned)blocks.base[b];
-        for (b = 0; b < blocks.n; b++, slot++)
-            f->fftItem[s][slot] = ((unsigned)SEA_BF_PI4 << 16) | (unsigned)(blocks.base[b] + n8);
+        /* plain / pi4 items use only i1 (+ multiples of n4); b repeats a so that the kernel's
+         * unconditional operand fetch stays inside the frame */
+        for (b = 0; b < blocks.n; b++, slot++) {
+            unsigned i1 = (unsigned)blocks.base[b];
+            f->fftItem[s][slot] = ((unsigned)SEA_BF_PLAIN << 16) | (i1 << 8) | i1;
+        }
+        for (b = 0; b < blocks.n; b++, slot++) {
+            unsigned i1 = (unsigned)(blocks.base[b] + n8);
+            f->fftItem[s][slot] = ((unsigned)SEA_BF_PI4 << 16) | (i1 << 8) | i1;
+        }
         if (slot > SEA_LANES) abort();
     }
 }

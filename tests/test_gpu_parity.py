@@ -255,3 +255,45 @@ def test_gammatone_filter_vs_oracle(oracle):
         got = sea.gammaToneFilter(x, chan)
         want = oracle.gammatone(x, cf[chan], bw[chan], me[chan])
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"channel {chan}"
+
+
+def test_selftest_pi4_identity_all_floats():
+    """The FFT's pi/4 butterfly multiplies by 1/sqrt2 in double instead of dividing by sqrt2: the
+    two give the same float for every one of the 2^32 float inputs (checked exhaustively here)."""
+    import ctypes
+    import speech_enhancement_amd as sea
+    _torch()
+    n = ctypes.c_ulonglong(123)
+    assert sea.load().sea_selftest_pi4(ctypes.byref(n)) == 0
+    assert n.value == 0, f"{n.value} floats differ"
+
+
+def test_selftest_dc_filter_fast_and_exact_paths():
+    """DC-offset recurrence: the float-FMA fast path must equal the reference's double arithmetic,
+    and frames whose operands could break that equivalence must take the exact path."""
+    import speech_enhancement_amd as sea
+    _torch()
+    rng = np.random.default_rng(7)
+    n = 64
+    dif = (rng.standard_normal((n, 80)) * rng.uniform(1e-3, 3e3, (n, 1))).astype(np.float32)
+    y0 = (rng.standard_normal(n) * 100).astype(np.float32)
+    dif[1] = 0.0                                     # all-zero differences (exact by construction)
+    dif[2, 40] = np.float32(1e-30)                   # tiny d against a large y: must fall back
+    y0[2] = np.float32(5e4)
+    dif[3, 0] = np.float32(3e9)                      # huge d against tiny y: must fall back
+    y0[3] = np.float32(1e-3)
+    y0[4] = 0.0
+    out = np.zeros_like(dif)
+    fb = np.zeros(n, np.int32)
+    lib = sea.load()
+    rc = lib.sea_selftest_dc(dif.ctypes.data, y0.ctypes.data, out.ctypes.data, fb.ctypes.data, n)
+    assert rc == 0
+    want = np.zeros_like(dif)
+    for c in range(n):
+        y = np.float32(y0[c])
+        for i in range(80):
+            y = np.float32(np.float64(dif[c, i]) + np.float64(0.9990234375) * np.float64(y))
+            want[c, i] = y
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    assert fb[2] == 1 and fb[3] == 1 and fb[1] == 0
+    print("dc fallbacks:", int(fb.sum()), "of", n)
