@@ -144,7 +144,16 @@ int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
     a.first_out = d_first_out;
     a.tables = c->ns;
     a.n_utt = n_utt;
-    hipLaunchKernelGGL(sea::ns_denoise_kernel, dim3(n_utt), dim3(64), 0, (hipStream_t)stream, a);
+    /* default: four pipelined wavefronts per utterance; SEA_NS_KERNEL=single selects the
+     * one-wavefront-per-utterance form of the same arithmetic (A/B timing, identical results) */
+    static const bool single = [] {
+        const char *e = getenv("SEA_NS_KERNEL");
+        return e && !strcmp(e, "single");
+    }();
+    if (single)
+        hipLaunchKernelGGL(sea::ns_denoise_kernel, dim3(n_utt), dim3(64), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(sea::ns_denoise_pipe_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,517 @@
+/*
+ * ns_core.h -- device code of the two-stage mel-warped Wiener noise suppressor shared by the
+ * NoiseSup kernels (ns_kernel.hip: one wavefront per utterance / stream; ns_pipe_kernel.hip: four
+ * pipelined wavefronts per utterance).  Everything is written for ONE 64-lane wavefront.
+ *
+ * Reference path reproduced (results bit-identical up to libm log/log10):
+ *   etsi/cpp/NoiseSup.c:1061-1440    DoNoiseSup          two stages, latency gates, buffers
+ *   etsi/cpp/NoiseSup.c:182-669      DCOffsetFil .. DoFilterWindowing
+ *   etsi/cpp/MelProc.c:82-104,357-378 DoMelFB, DoMelIDCT
+ *   etsi/cpp/rfft.c:45-180           rfft (sea_device.h)
+ */
+#pragma once
+#include "sea_device.h"
+#include "sea_kernels.h"
+
+namespace sea {
+
+namespace {
+
+constexpr int kRing = 320;
+constexpr double kLn2 = 0.69314718055994530942; /* log(2.0) */
+
+/* scratch of the "back" half of a stage (everything after the PSD) */
+struct __attribute__((aligned(16))) BackLds {
+    float wbuf[68];       /* Wiener gains W[65] */
+    float sbuf[68];       /* spectrum to be summed in order (denSigSE1 / noiseSE2) */
+    float sq[80];         /* VAD: squared samples; DC filter: differences */
+    float mel[28];        /* 25 mel gains */
+    float fir[20];        /* 17 filter taps */
+};
+
+/* LDS of the single-wave form (streaming kernel): both stages share the scratch */
+struct __attribute__((aligned(16))) NsLds {
+    float ring[2][kRing]; /* First/SecondStageInFloatBuffer, NoiseSup.c:98-99 */
+    float work[256];      /* FFT workspace */
+    float psd[68];        /* 65 PSD bins handed from the front half to the back half */
+    BackLds back;
+    float outb[80];       /* second-stage filter output, then DC-filtered output */
+};
+
+/* per-lane constants (sea_ns_tables columns) */
+struct NsConst {
+    FftRegs fft;
+    float win[4];
+    int melStart, melLen;
+    float melW[SEA_MEL_TAPS];
+    float idct[SEA_NMEL];
+    float irWin;
+    float eps;
+};
+
+/* per-utterance recursive state that is not in LDS */
+struct NsRegs {
+    /* per bin: [stage]; "Lo" = bin lane (0..63), "Hi" = bin 64 (meaningful in lane 0) */
+    float noiseLo[2], noiseHi[2];   /* noiseSE1/2 */
+    float denLo[2], denHi[2];       /* denSigSE1/2 */
+    float prevLo[2], prevHi[2];     /* other slot of PSDMeanBuffer1/2 = previous frame's PSD */
+    /* wave-uniform scalars */
+    float dcX, dcY;                 /* prevSamples */
+    float denEn0, denEn1, denEn2, lowSNRtrack, alfaGF;
+    float meanEn;
+    int nbFrame[2];
+    int flagVAD, hangOver, nbSpeech; /* X_INT16 in the reference */
+    int nIn1, nIn2, nOut2;
+    int onset;
+};
+
+__device__ __forceinline__ void regs_init(NsRegs &s, float eps)
+{ /* DoNoiseSupInit, NoiseSup.c:884-968 */
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        s.noiseLo[st] = s.noiseHi[st] = eps;
+        s.denLo[st] = s.denHi[st] = 0.0f;
+        s.prevLo[st] = s.prevHi[st] = 0.0f;
+        s.nbFrame[st] = 0;
+    }
+    s.dcX = s.dcY = 0.0f;
+    s.denEn0 = s.denEn1 = s.denEn2 = 0.0f;
+    s.lowSNRtrack = 0.0f;
+    s.alfaGF = (float)0.8;
+    s.meanEn = 0.0f;
+    s.flagVAD = s.hangOver = s.nbSpeech = 0;
+    s.nIn1 = s.nIn2 = s.nOut2 = 0;
+    s.onset = 0;
+}
+
+__device__ __forceinline__ float uniform_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+/* One PSD bin of FilterCalc (NoiseSup.c:449-563).  P = 2-frame mean PSD, nSig = this frame's PSD.
+ * nb is the frame counter narrowed to int16 as the reference does. */
+template <int ST>
+__device__ __forceinline__ float filter_bin(float P, float nSig, float &noise, float &den, int nb,
+                                            int flagVAD, float eps)
+{
+    if (ST == 1) { /* non-VAD noise tracking in the energy domain, :486-517 */
+        float n2 = noise * noise;
+        if (nb < 11) {
+            const float lambda = 1 - 1 / (float)nb;
+            n2 = lambda * n2 + (1 - lambda) * P;
+        } else {
+            const float r1 = P / (P + n2), r2 = P / n2;
+            const float upd = (float)(0.9 + 0.1 * (double)r1 * (1.0 + 1.0 / (1.0 + 0.1 * (double)r2)));
+            n2 *= upd;
+        }
+        n2 = sqrtf(n2);
+        noise = (n2 < eps) ? eps : n2;
+    }
+    nSig = sqrtf(nSig); /* :522-526, (float)sqrt((double)x) == correctly rounded sqrtf */
+    P = sqrtf(P);
+    if (ST == 0) { /* VAD-gated noise tracking in magnitude, :531-546 */
+        const float lambda = (nb < 100) ? 1 - 1 / (float)nb : (float)0.99;
+        if (flagVAD == 0) {
+            const float n = lambda * noise + (1 - lambda) * P;
+            noise = (n < eps) ? eps : n;
+        }
+    }
+    /* :551-560 */
+    const float beta = (float)0.98, rsbMin = (float)0.079432823;
+    const float post = (P / noise) - 1;
+    float prio = beta * (den / noise) + (1 - beta) * ((0 > post) ? 0 : post);
+    float W = prio / (1 + prio);
+    prio = W * P / noise;
+    prio = (prio > rsbMin) ? prio : rsbMin;
+    W = prio / (1 + prio);
+    den = W * nSig;
+    return W;
+}
+
+/* VAD for noise suppression, NoiseSup.c:359-430 (first stage only does work) */
+__device__ __forceinline__ void vad_update(NsRegs &s, float frameSum)
+{
+    const int nb = s.nbFrame[0];
+    const float lambdaLTE = (nb < 10) ? 1 - 1 / (float)nb : (float)0.97;
+    const float frameEn = uniform_f((float)(0.5 + (log((double)frameSum / 64.0) / kLn2) * 16.0));
+    float meanEn = s.meanEn;
+    if (((frameEn - meanEn) < 20.0f) || (nb < 10)) {
+        if ((frameEn < meanEn) || (nb < 10))
+            meanEn += (1 - lambdaLTE) * (frameEn - meanEn);
+        else
+            meanEn += (1 - (float)0.99) * (frameEn - meanEn);
+        if (meanEn < 80.0f) meanEn = 80.0f;
+    }
+    if (nb > 4) {
+        if ((frameEn - meanEn) > 15.0f) {
+            s.flagVAD = 1;
+            s.nbSpeech = (short)(s.nbSpeech + 1);
+        } else {
+            if (s.nbSpeech > 4) s.hangOver = 15;
+            s.nbSpeech = 0;
+            if (s.hangOver != 0) {
+                s.hangOver--;
+                s.flagVAD = 1;
+            } else
+                s.flagVAD = 0;
+        }
+    }
+    s.meanEn = meanEn;
+}
+
+/* second-stage gain factorisation scalars, NoiseSup.c:600-637; returns alfaGF */
+__device__ __forceinline__ void gain_fact_update(NsRegs &s, float noiseEn)
+{
+    float averSNR = (s.denEn0 * s.denEn1 * s.denEn2) / (noiseEn * noiseEn * noiseEn);
+    if ((double)averSNR > 0.00001)
+        averSNR = (float)((20 * log10((double)averSNR)) / 3.0);
+    else
+        averSNR = (float)(-100.0 / 3.0);
+    averSNR = uniform_f(averSNR);
+    const int nb = s.nbFrame[1];
+    if (((double)(averSNR - s.lowSNRtrack) < 10.0) || (nb < 10)) {
+        float lambdaSNR;
+        if (nb < 10)
+            lambdaSNR = (float)(1.0 - 1.0 / (double)(float)nb);
+        else
+            lambdaSNR = (averSNR < s.lowSNRtrack) ? (float)0.95 : (float)0.99;
+        s.lowSNRtrack =
+            (float)((double)s.lowSNRtrack + (1.0 - (double)lambdaSNR) * (double)(averSNR - s.lowSNRtrack));
+    }
+    if (s.denEn2 > 100.0f) {
+        if ((double)averSNR < ((double)s.lowSNRtrack + 3.5)) {
+            s.alfaGF = (float)((double)s.alfaGF + 0.15);
+            if ((double)s.alfaGF > 0.8) s.alfaGF = (float)0.8;
+        } else {
+            s.alfaGF = (float)((double)s.alfaGF - 0.3);
+            if ((double)s.alfaGF < 0.1) s.alfaGF = (float)0.1;
+        }
+    }
+}
+
+/* FRONT half of a stage: analysis window on buf[60..259] (buf = 320-sample stage buffer, zero
+ * padded to 256: NoiseSup.c:218-231), 256-point rfft, FFTtoPSD (129 power bins averaged pairwise to
+ * 65: NoiseSup.c:249-270).  Depends on the buffer only -- no recursive state -- which is what lets
+ * the pipelined kernel give it a wavefront of its own.  Writes psd[0..64]; ends with wave_sync(). */
+__device__ __forceinline__ void ns_front(const float *buf, float *work, float *psd, const FftRegs &fft,
+                                         const float (&win)[4], int lane)
+{
+    const float e0 = buf[60 + lane] * win[0];
+    const float e1 = buf[124 + lane] * win[1];
+    const float e2 = buf[188 + lane] * win[2];
+    const float e3 = (lane < 8) ? buf[252 + lane] * win[3] : 0.0f;
+    rfft256(e0, e1, e2, e3, work, fft, lane);
+    const float re0 = work[2 * lane], re1 = work[2 * lane + 1];
+    const float im1 = work[255 - 2 * lane];
+    const float im0 = (lane > 0) ? work[256 - 2 * lane] : 0.0f;
+    const float p0 = (lane > 0) ? (re0 * re0 + im0 * im0) : (re0 * re0);
+    const float p1 = re1 * re1 + im1 * im1;
+    psd[lane] = (p0 + p1) * 0.5f; /* == (float)((p0+p1)/2.0) */
+    if (lane == 0) {
+        const float ny = work[128];
+        psd[64] = ny * ny;
+    }
+    wave_sync();
+}
+
+/* BACK half of a stage (ST = 0 first, 1 second): everything recursive.  Consumes psd[0..64] and
+ * the stage buffer (raw frame buf[80..159] for the VAD, buf[72..167] for the FIR), updates the
+ * per-utterance state and deposits the 80 filtered samples in dst.  Ends with wave_sync(). */
+template <int ST>
+__device__ __forceinline__ void ns_back(const float *psd, const float *buf, BackLds &B, NsRegs &s,
+                                        const NsConst &C, float *dst, int lane)
+{
+    const float nSigLo = psd[lane], nSigHi = psd[64];
+
+    /* --- VAD frame energy terms (first stage; needs only the raw frame buf[80..159]) --- */
+    if (ST == 0) {
+        const float x = buf[80 + lane];
+        B.sq[lane] = x * x;
+        if (lane < 16) {
+            const float y = buf[144 + lane];
+            B.sq[64 + lane] = y * y;
+        }
+        wave_sync();
+    }
+    /* --- PSDMean over two frames (NoiseSup.c:289-303) --- */
+    const float PLo = (s.prevLo[ST] + nSigLo) * 0.5f;
+    const float PHi = (s.prevHi[ST] + nSigHi) * 0.5f;
+    s.prevLo[ST] = nSigLo;
+    s.prevHi[ST] = nSigHi;
+
+    /* --- VAD (NoiseSup.c:359-430) --- */
+    {
+        int nb = s.nbFrame[ST];
+        if (nb < 2147483647) nb++;
+        s.nbFrame[ST] = nb;
+    }
+    if (ST == 0) {
+#ifdef SEA_ABLATE_VADSUM
+        const float frameSum = 64.0f + B.sq[0] + B.sq[79];
+#else
+        const float frameSum = serial_sum<80>(B.sq, 64.0f);
+#endif
+        vad_update(s, frameSum);
+    }
+
+    /* --- FilterCalc (NoiseSup.c:449-563): bins 0..63 on all lanes, bin 64 on lane 0 --- */
+    const int nb16 = (int)(short)s.nbFrame[ST];
+    const float WLo = filter_bin<ST>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
+    B.wbuf[lane] = WLo;
+    B.sbuf[lane] = (ST == 0) ? s.denLo[0] : s.noiseLo[1];
+#ifndef SEA_ABLATE_HI
+    if (lane == 0) {
+        const float WHi = filter_bin<ST>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
+        B.wbuf[64] = WHi;
+        B.sbuf[64] = (ST == 0) ? s.denHi[0] : s.noiseHi[1];
+    }
+#endif
+    wave_sync();
+
+    /* --- DoMelFB: 25 bands, taps in order (MelProc.c:82-104) --- */
+    float melOut = 0.0f;
+    if (lane < SEA_NMEL) {
+#pragma unroll
+        for (int i = 0; i < SEA_MEL_TAPS; ++i) {
+            const int idx = C.melStart + i;
+            const float t = melOut + B.wbuf[idx < 65 ? idx : 64] * C.melW[i];
+            melOut = (i < C.melLen) ? t : melOut;
+        }
+    }
+
+    /* --- DoGainFact (NoiseSup.c:581-642) --- */
+#ifdef SEA_ABLATE_GSUM
+    const float total = B.sbuf[0] + B.sbuf[64];
+#else
+    const float total = serial_sum<65>(B.sbuf, 0.0f);
+#endif
+    if (ST == 0) {
+        s.denEn0 = s.denEn1;
+        s.denEn1 = s.denEn2;
+        s.denEn2 = total;
+    } else {
+        gain_fact_update(s, total);
+        melOut = (float)((double)(s.alfaGF * melOut) + (1.0 - (double)s.alfaGF) * 1.0);
+    }
+    if (lane < SEA_NMEL) B.mel[lane] = melOut;
+    wave_sync();
+
+    /* --- DoMelIDCT rows 0..8 (MelProc.c:357-378), mirror + Hanning(17) (NoiseSup.c:660-669) --- */
+    if (lane <= 8) {
+        float h = 0.0f;
+#pragma unroll
+        for (int f = 0; f < SEA_NMEL; ++f) h += B.mel[f] * C.idct[f];
+        const float tap = h * C.irWin;
+        B.fir[8 + lane] = tap;
+        B.fir[8 - lane] = tap;
+    }
+    wave_sync();
+
+    /* --- ApplyWF: 17-tap FIR over buf[80..159] with 8 samples context either side
+     *     (NoiseSup.c:324-340); lanes 0..39 produce two outputs each --- */
+    if (lane < 40) {
+        float c[SEA_NTAP];
+#pragma unroll
+        for (int k = 0; k < SEA_NTAP; ++k) c[k] = B.fir[k];
+        float x[18];
+        const float *src = buf + 72 + 2 * lane; /* x[m] = buf[72 + 2l + m] */
+#pragma unroll
+        for (int m = 0; m < 18; m += 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(src + m);
+            x[m] = v.x;
+            x[m + 1] = v.y;
+        }
+        float y0 = 0.0f, y1 = 0.0f;
+        /* out[i] = sum_{j=-8..8} fir[j+8] * buf[80+i-j]; i = 2l -> buf index 72+2l+(8-j) */
+#pragma unroll
+        for (int k = 0; k < SEA_NTAP; ++k) {
+            y0 += c[k] * x[16 - k];
+            y1 += c[k] * x[17 - k];
+        }
+        *reinterpret_cast<float2 *>(dst + 2 * lane) = make_float2(y0, y1);
+    }
+    wave_sync();
+}
+
+/* One whole stage on the single-wave form: stage 0 deposits its 80 output samples in
+ * ring[1][240..319], stage 1 in outb[0..79]. */
+template <int ST>
+__device__ __forceinline__ void ns_stage(NsLds &L, NsRegs &s, const NsConst &C, int lane)
+{
+    ns_front(L.ring[ST], L.work, L.psd, C.fft, C.win, lane);
+    ns_back<ST>(L.psd, L.ring[ST], L.back, s, C, (ST == 0) ? (L.ring[1] + 240) : L.outb, lane);
+}
+
+/* DCOffsetFil over one frame (NoiseSup.c:182-198): y[n] = float( double(d[n]) + 0.9990234375 *
+ * double(y[n-1]) ), d[n] = x[n] - x[n-1] already in dif[0..79]; writes y to out[0..79], updates yState.
+ * An 80-step serial recurrence (all lanes compute it redundantly).
+ *
+ * The reference rounds twice per sample (sum to double, then to float).  Whenever the exact value
+ * d + c*y (c = 1023/1024, so c*y has at most 34 significant bits) fits a double exactly, that
+ * equals ONE rounding to float, which a float FMA delivers with a 3x shorter dependency chain.
+ * "Fits exactly" holds when the exponents of d and y are within [-16, +26] of each other (or
+ * either is 0); that is verified for all 80 samples in parallel afterwards, and the frame is
+ * recomputed on the exact double path in the (never yet observed) case that a sample fails. */
+__device__ __forceinline__ bool dc_filter(const float *dif, float *out, float &yState, int lane)
+{
+    const float y0 = yState;
+    float y = y0;
+#ifdef SEA_ABLATE_DC
+    for (int n = 0; n < 4; n += 4) {
+#else
+#pragma unroll 5
+    for (int n = 0; n < SEA_HOP; n += 4) {
+#endif
+        const float4 d = *reinterpret_cast<const float4 *>(&dif[n]);
+        float4 o;
+        y = __fmaf_rn(0.9990234375f, y, d.x);
+        o.x = y;
+        y = __fmaf_rn(0.9990234375f, y, d.y);
+        o.y = y;
+        y = __fmaf_rn(0.9990234375f, y, d.z);
+        o.z = y;
+        y = __fmaf_rn(0.9990234375f, y, d.w);
+        o.w = y;
+        *reinterpret_cast<float4 *>(&out[n]) = o;
+    }
+    wave_sync();
+    bool unsafe = false;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int n = lane + 64 * k;
+        if (n < SEA_HOP) {
+            const float ad = fabsf(dif[n]);
+            const float ay = fabsf(n == 0 ? y0 : out[n - 1]);
+            const bool ok = (ad == 0.0f) || (ay == 0.0f) ||
+                            (ay >= ad * 0x1p-16f && ay <= ad * 0x1p26f && ad < 0x1p100f && ad > 0x1p-100f);
+            unsafe |= !ok;
+        }
+    }
+    const bool redo = __ballot(unsafe) != 0ull;
+    if (redo) { /* exact path: double multiply-add, rounded to float per sample */
+        wave_sync();
+        y = y0;
+        for (int n = 0; n < SEA_HOP; ++n) {
+            y = (float)__fma_rn(0.9990234375, (double)y, (double)dif[n]);
+            out[n] = y;
+        }
+    }
+    yState = y;
+    wave_sync();
+    return redo;
+}
+
+/* DoNoiseSup (NoiseSup.c:1061-1440) for one 80-sample frame.  Lanes 0..39 pass samples 2l and
+ * 2l+1.  Returns true when L.outb[0..79] holds a DC-filtered output frame. */
+__device__ __forceinline__ bool ns_tick(NsLds &L, NsRegs &s, const NsConst &C, int lane, float x0, float x1)
+{
+    if (lane < 40) *reinterpret_cast<float2 *>(&L.ring[0][240 + 2 * lane]) = make_float2(x0, x1);
+    wave_sync();
+    s.nIn1++;
+    if (s.nIn1 - s.nIn2 > 2) { /* NoiseSup.c:1152 */
+        ns_stage<0>(L, s, C, lane);
+        s.nIn2++;
+    }
+    if (s.nIn2 - s.nOut2 > 2) { /* NoiseSup.c:1178 */
+        ns_stage<1>(L, s, C, lane);
+        s.nOut2++;
+    }
+    /* slide both buffers by one hop (NoiseSup.c:1372-1390) */
+    {
+        float4 r0, r1;
+        if (lane < 60) {
+            r0 = *reinterpret_cast<const float4 *>(&L.ring[0][80 + 4 * lane]);
+            r1 = *reinterpret_cast<const float4 *>(&L.ring[1][80 + 4 * lane]);
+        }
+        wave_sync();
+        if (lane < 60) {
+            *reinterpret_cast<float4 *>(&L.ring[0][4 * lane]) = r0;
+            *reinterpret_cast<float4 *>(&L.ring[1][4 * lane]) = r1;
+        }
+    }
+    if (s.nOut2 <= 0) {
+        wave_sync();
+        return false;
+    }
+    /* DCOffsetFil (NoiseSup.c:182-198): differences in parallel, recurrence in dc_filter() */
+    {
+        const float xm1 = (lane == 0) ? s.dcX : L.outb[lane - 1];
+        const float d0 = L.outb[lane] - xm1;
+        float d1 = 0.0f;
+        if (lane < 16) d1 = L.outb[64 + lane] - L.outb[63 + lane];
+        s.dcX = L.outb[79];
+        wave_sync();
+        L.back.sq[lane] = d0;
+        if (lane < 16) L.back.sq[64 + lane] = d1;
+    }
+    wave_sync();
+    dc_filter(L.back.sq, L.outb, s.dcY, lane);
+    return true;
+}
+
+__device__ __forceinline__ void load_ns_const(NsConst &C, const sea_ns_tables *t, int lane)
+{
+    load_fft_regs(C.fft, &t->fft, lane);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) C.win[k] = t->win[k][lane];
+    C.melStart = t->melStart[lane];
+    C.melLen = t->melLen[lane];
+#pragma unroll
+    for (int i = 0; i < SEA_MEL_TAPS; ++i) C.melW[i] = t->melW[i][lane];
+#pragma unroll
+    for (int f = 0; f < SEA_NMEL; ++f) C.idct[f] = t->idct[f][lane];
+    C.irWin = t->irWin[lane];
+    C.eps = t->eps;
+}
+
+/* ---- state blob of a stream (sea_ns_stream_*): [640 ring][12 x 64 per-lane][32 scalars] ---- */
+constexpr int kBlobLane = 2 * kRing, kBlobScal = kBlobLane + 12 * 64;
+
+__device__ __forceinline__ void state_store(float *blob, const NsLds &L, const NsRegs &s, int lane)
+{
+    for (int i = lane; i < 2 * kRing; i += kLanes) blob[i] = (&L.ring[0][0])[i];
+    float *p = blob + kBlobLane + lane;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        p[(0 + st) * 64] = s.noiseLo[st];
+        p[(2 + st) * 64] = s.noiseHi[st];
+        p[(4 + st) * 64] = s.denLo[st];
+        p[(6 + st) * 64] = s.denHi[st];
+        p[(8 + st) * 64] = s.prevLo[st];
+        p[(10 + st) * 64] = s.prevHi[st];
+    }
+    if (lane == 0) {
+        float *q = blob + kBlobScal;
+        int *qi = reinterpret_cast<int *>(q + 16);
+        q[0] = s.dcX; q[1] = s.dcY; q[2] = s.denEn0; q[3] = s.denEn1; q[4] = s.denEn2;
+        q[5] = s.lowSNRtrack; q[6] = s.alfaGF; q[7] = s.meanEn;
+        qi[0] = s.nbFrame[0]; qi[1] = s.nbFrame[1]; qi[2] = s.flagVAD; qi[3] = s.hangOver;
+        qi[4] = s.nbSpeech; qi[5] = s.nIn1; qi[6] = s.nIn2; qi[7] = s.nOut2; qi[8] = s.onset;
+    }
+}
+
+__device__ __forceinline__ void state_load(const float *blob, NsLds &L, NsRegs &s, int lane)
+{
+    for (int i = lane; i < 2 * kRing; i += kLanes) (&L.ring[0][0])[i] = blob[i];
+    const float *p = blob + kBlobLane + lane;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        s.noiseLo[st] = p[(0 + st) * 64];
+        s.noiseHi[st] = p[(2 + st) * 64];
+        s.denLo[st] = p[(4 + st) * 64];
+        s.denHi[st] = p[(6 + st) * 64];
+        s.prevLo[st] = p[(8 + st) * 64];
+        s.prevHi[st] = p[(10 + st) * 64];
+    }
+    const float *q = blob + kBlobScal;
+    const int *qi = reinterpret_cast<const int *>(q + 16);
+    s.dcX = q[0]; s.dcY = q[1]; s.denEn0 = q[2]; s.denEn1 = q[3]; s.denEn2 = q[4];
+    s.lowSNRtrack = q[5]; s.alfaGF = q[6]; s.meanEn = q[7];
+    s.nbFrame[0] = qi[0]; s.nbFrame[1] = qi[1]; s.flagVAD = qi[2]; s.hangOver = qi[3];
+    s.nbSpeech = qi[4]; s.nIn1 = qi[5]; s.nIn2 = qi[6]; s.nOut2 = qi[7]; s.onset = qi[8];
+}
+
+} // namespace
+
+} // namespace sea

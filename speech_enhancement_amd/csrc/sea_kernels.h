@@ -62,6 +62,7 @@ struct ResynthArgs {
 };
 
 __global__ void ns_denoise_kernel(NsBatchArgs a);
+__global__ void ns_denoise_pipe_kernel(NsBatchArgs a);
 __global__ void ns_stream_kernel(NsStreamArgs a);
 __global__ void selftest_pi4_kernel(unsigned long long *mismatches);
 __global__ void selftest_dc_kernel(const float *dif, const float *y0, float *out, int *fellback, int ncases);
