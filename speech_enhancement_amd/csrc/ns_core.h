@@ -129,12 +129,35 @@ __device__ __forceinline__ float filter_bin(float P, float nSig, float &noise, f
     return W;
 }
 
+/* VAD frame log-energy (NoiseSup.c:386-391) from 64 + sum of the 80 squared samples: depends on
+ * the raw frame only, so the pipelined kernel computes it in its helper wave */
+__device__ __forceinline__ float vad_frame_energy(float frameSum)
+{
+    return uniform_f((float)(0.5 + (log((double)frameSum / 64.0) / kLn2) * 16.0));
+}
+
+/* squares of the raw frame frame[0..79] -> sq[0..79], then the in-order sum (all lanes) */
+__device__ __forceinline__ float vad_frame_sum(const float *frame, float *sq, int lane)
+{
+    const float x = frame[lane];
+    sq[lane] = x * x;
+    if (lane < 16) {
+        const float y = frame[64 + lane];
+        sq[64 + lane] = y * y;
+    }
+    wave_sync();
+#ifdef SEA_ABLATE_VADSUM
+    return 64.0f + sq[0] + sq[79];
+#else
+    return serial_sum<80>(sq, 64.0f);
+#endif
+}
+
 /* VAD for noise suppression, NoiseSup.c:359-430 (first stage only does work) */
-__device__ __forceinline__ void vad_update(NsRegs &s, float frameSum)
+__device__ __forceinline__ void vad_update(NsRegs &s, float frameEn)
 {
     const int nb = s.nbFrame[0];
     const float lambdaLTE = (nb < 10) ? 1 - 1 / (float)nb : (float)0.97;
-    const float frameEn = uniform_f((float)(0.5 + (log((double)frameSum / 64.0) / kLn2) * 16.0));
     float meanEn = s.meanEn;
     if (((frameEn - meanEn) < 20.0f) || (nb < 10)) {
         if ((frameEn < meanEn) || (nb < 10))
@@ -217,23 +240,19 @@ __device__ __forceinline__ void ns_front(const float *buf, float *work, float *p
 
 /* BACK half of a stage (ST = 0 first, 1 second): everything recursive.  Consumes psd[0..64] and
  * the stage buffer (raw frame buf[80..159] for the VAD, buf[72..167] for the FIR), updates the
- * per-utterance state and deposits the 80 filtered samples in dst.  Ends with wave_sync(). */
-template <int ST>
+ * per-utterance state and deposits the 80 filtered samples in dst.  Ends with wave_sync().
+ *
+ * PIPE = true (pipelined kernel): the input-only / deferrable scalar chains run in a helper wave.
+ *   ST 0: the VAD frame log-energy arrives in frameEnExt; the 65 denSigSE1 values go to spectOut
+ *         (summed later by the helper), the denEn registers are not touched.
+ *   ST 1: the caller has loaded s.denEn0..2. */
+template <int ST, bool PIPE>
 __device__ __forceinline__ void ns_back(const float *psd, const float *buf, BackLds &B, NsRegs &s,
-                                        const NsConst &C, float *dst, int lane)
+                                        const NsConst &C, float *dst, int lane, float frameEnExt = 0.0f,
+                                        float *spectOut = nullptr)
 {
     const float nSigLo = psd[lane], nSigHi = psd[64];
 
-    /* --- VAD frame energy terms (first stage; needs only the raw frame buf[80..159]) --- */
-    if (ST == 0) {
-        const float x = buf[80 + lane];
-        B.sq[lane] = x * x;
-        if (lane < 16) {
-            const float y = buf[144 + lane];
-            B.sq[64 + lane] = y * y;
-        }
-        wave_sync();
-    }
     /* --- PSDMean over two frames (NoiseSup.c:289-303) --- */
     const float PLo = (s.prevLo[ST] + nSigLo) * 0.5f;
     const float PHi = (s.prevHi[ST] + nSigHi) * 0.5f;
@@ -247,26 +266,27 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
         s.nbFrame[ST] = nb;
     }
     if (ST == 0) {
-#ifdef SEA_ABLATE_VADSUM
-        const float frameSum = 64.0f + B.sq[0] + B.sq[79];
-#else
-        const float frameSum = serial_sum<80>(B.sq, 64.0f);
-#endif
-        vad_update(s, frameSum);
+        const float frameEn = PIPE ? frameEnExt : vad_frame_energy(vad_frame_sum(buf + 80, B.sq, lane));
+        vad_update(s, frameEn);
     }
 
-    /* --- FilterCalc (NoiseSup.c:449-563): bins 0..63 on all lanes, bin 64 on lane 0 --- */
+    /* --- FilterCalc (NoiseSup.c:449-563): bins 0..63 one per lane; bin 64 is computed by EVERY lane
+     *     (same cost as one predicated lane, but branch-free, so the two independent chains
+     *     interleave) --- */
     const int nb16 = (int)(short)s.nbFrame[ST];
     const float WLo = filter_bin<ST>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
-    B.wbuf[lane] = WLo;
-    B.sbuf[lane] = (ST == 0) ? s.denLo[0] : s.noiseLo[1];
 #ifndef SEA_ABLATE_HI
-    if (lane == 0) {
-        const float WHi = filter_bin<ST>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
-        B.wbuf[64] = WHi;
-        B.sbuf[64] = (ST == 0) ? s.denHi[0] : s.noiseHi[1];
-    }
+    const float WHi = filter_bin<ST>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
+#else
+    const float WHi = PHi;
 #endif
+    float *spect = (PIPE && ST == 0) ? spectOut : B.sbuf;
+    B.wbuf[lane] = WLo;
+    spect[lane] = (ST == 0) ? s.denLo[0] : s.noiseLo[1];
+    if (lane == 0) {
+        B.wbuf[64] = WHi;
+        spect[64] = (ST == 0) ? s.denHi[0] : s.noiseHi[1];
+    }
     wave_sync();
 
     /* --- DoMelFB: 25 bands, taps in order (MelProc.c:82-104) --- */
@@ -281,27 +301,37 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     }
 
     /* --- DoGainFact (NoiseSup.c:581-642) --- */
+    if (!(PIPE && ST == 0)) {
 #ifdef SEA_ABLATE_GSUM
-    const float total = B.sbuf[0] + B.sbuf[64];
+        const float total = B.sbuf[0] + B.sbuf[64];
 #else
-    const float total = serial_sum<65>(B.sbuf, 0.0f);
+        const float total = serial_sum<65>(B.sbuf, 0.0f);
 #endif
-    if (ST == 0) {
-        s.denEn0 = s.denEn1;
-        s.denEn1 = s.denEn2;
-        s.denEn2 = total;
-    } else {
-        gain_fact_update(s, total);
-        melOut = (float)((double)(s.alfaGF * melOut) + (1.0 - (double)s.alfaGF) * 1.0);
+        if (ST == 0) {
+            s.denEn0 = s.denEn1;
+            s.denEn1 = s.denEn2;
+            s.denEn2 = total;
+        } else {
+            gain_fact_update(s, total);
+            melOut = (float)((double)(s.alfaGF * melOut) + (1.0 - (double)s.alfaGF) * 1.0);
+        }
     }
     if (lane < SEA_NMEL) B.mel[lane] = melOut;
+    if (lane >= SEA_NMEL && lane < 28) B.mel[lane] = 0.0f; /* padding read by the float4 loads below */
     wave_sync();
 
     /* --- DoMelIDCT rows 0..8 (MelProc.c:357-378), mirror + Hanning(17) (NoiseSup.c:660-669) --- */
     if (lane <= 8) {
         float h = 0.0f;
 #pragma unroll
-        for (int f = 0; f < SEA_NMEL; ++f) h += B.mel[f] * C.idct[f];
+        for (int f4 = 0; f4 < 24; f4 += 4) {
+            const float4 m = *reinterpret_cast<const float4 *>(&B.mel[f4]);
+            h += m.x * C.idct[f4];
+            h += m.y * C.idct[f4 + 1];
+            h += m.z * C.idct[f4 + 2];
+            h += m.w * C.idct[f4 + 3];
+        }
+        h += B.mel[24] * C.idct[24];
         const float tap = h * C.irWin;
         B.fir[8 + lane] = tap;
         B.fir[8 - lane] = tap;
@@ -309,27 +339,37 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     wave_sync();
 
     /* --- ApplyWF: 17-tap FIR over buf[80..159] with 8 samples context either side
-     *     (NoiseSup.c:324-340); lanes 0..39 produce two outputs each --- */
-    if (lane < 40) {
+     *     (NoiseSup.c:324-340); lanes 0..39 produce two outputs each.  The taps are wave-uniform:
+     *     they are moved to scalar registers --- */
+    {
         float c[SEA_NTAP];
 #pragma unroll
-        for (int k = 0; k < SEA_NTAP; ++k) c[k] = B.fir[k];
-        float x[18];
-        const float *src = buf + 72 + 2 * lane; /* x[m] = buf[72 + 2l + m] */
-#pragma unroll
-        for (int m = 0; m < 18; m += 2) {
-            const float2 v = *reinterpret_cast<const float2 *>(src + m);
-            x[m] = v.x;
-            x[m + 1] = v.y;
+        for (int k4 = 0; k4 < 16; k4 += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(&B.fir[k4]);
+            c[k4] = uniform_f(v.x);
+            c[k4 + 1] = uniform_f(v.y);
+            c[k4 + 2] = uniform_f(v.z);
+            c[k4 + 3] = uniform_f(v.w);
         }
-        float y0 = 0.0f, y1 = 0.0f;
-        /* out[i] = sum_{j=-8..8} fir[j+8] * buf[80+i-j]; i = 2l -> buf index 72+2l+(8-j) */
+        c[16] = uniform_f(B.fir[16]);
+        if (lane < 40) {
+            float x[18];
+            const float *src = buf + 72 + 2 * lane; /* x[m] = buf[72 + 2l + m] */
 #pragma unroll
-        for (int k = 0; k < SEA_NTAP; ++k) {
-            y0 += c[k] * x[16 - k];
-            y1 += c[k] * x[17 - k];
+            for (int m = 0; m < 18; m += 2) {
+                const float2 v = *reinterpret_cast<const float2 *>(src + m);
+                x[m] = v.x;
+                x[m + 1] = v.y;
+            }
+            float y0 = 0.0f, y1 = 0.0f;
+            /* out[i] = sum_{j=-8..8} fir[j+8] * buf[80+i-j]; i = 2l -> buf index 72+2l+(8-j) */
+#pragma unroll
+            for (int k = 0; k < SEA_NTAP; ++k) {
+                y0 += c[k] * x[16 - k];
+                y1 += c[k] * x[17 - k];
+            }
+            *reinterpret_cast<float2 *>(dst + 2 * lane) = make_float2(y0, y1);
         }
-        *reinterpret_cast<float2 *>(dst + 2 * lane) = make_float2(y0, y1);
     }
     wave_sync();
 }
@@ -340,7 +380,7 @@ template <int ST>
 __device__ __forceinline__ void ns_stage(NsLds &L, NsRegs &s, const NsConst &C, int lane)
 {
     ns_front(L.ring[ST], L.work, L.psd, C.fft, C.win, lane);
-    ns_back<ST>(L.psd, L.ring[ST], L.back, s, C, (ST == 0) ? (L.ring[1] + 240) : L.outb, lane);
+    ns_back<ST, false>(L.psd, L.ring[ST], L.back, s, C, (ST == 0) ? (L.ring[1] + 240) : L.outb, lane);
 }
 
 /* DCOffsetFil over one frame (NoiseSup.c:182-198): y[n] = float( double(d[n]) + 0.9990234375 *

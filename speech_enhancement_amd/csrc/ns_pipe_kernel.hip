@@ -1,23 +1,27 @@
 /*
- * ns_pipe_kernel.hip -- etsi_denoise over a packed batch, FOUR PIPELINED WAVEFRONTS per utterance.
+ * ns_pipe_kernel.hip -- etsi_denoise over a packed batch, FIVE PIPELINED WAVEFRONTS per utterance.
  *
  * Frames of one utterance are serially dependent, so a batch of N utterances offers
  * only N independent chains: at BASELINE configs[1] (1024 utterances on 1024 SIMDs) a
  * one-wave-per-utterance kernel leaves every SIMD with a single latency-bound wave.  The frame
- * recursion however is a 4-deep software pipeline, and this kernel gives each depth its own wave
- * (workgroup = 256 threads = one utterance; the four waves land on the four SIMDs of a CU):
+ * recursion however is a software pipeline, and this kernel gives each depth its own wave
+ * (workgroup = 320 threads = one utterance), one s_barrier per frame:
  *
- *   wave 0  frame f     load int16, zero-frame gate, push into stage-0 buffer, window+rfft+PSD  (FRONT 0)
- *   wave 1  frame f-1   VAD, FilterCalc, mel, gain, IDCT, 17-tap FIR of stage 0                 (BACK 0)
- *   wave 2  frame f-2   window+rfft+PSD of the stage-1 buffer                                   (FRONT 1)
- *   wave 3  frame f-3   stage-1 FilterCalc .. FIR, DC-offset filter, int16 cast, store          (BACK 1)
+ *   wave F0  frame i     load int16, zero-frame gate, push into stage-0 buffer, window+rfft+PSD
+ *   wave B0  frame i-1   stage-0 FilterCalc, mel, IDCT, 17-tap FIR  -> stage-1 buffer
+ *   wave F1  frame i-2   window+rfft+PSD of the stage-1 buffer
+ *   wave B1  frame i-3   stage-1 FilterCalc, gain factorisation, mel, IDCT, FIR
+ *   wave S   the lane-redundant scalar chains that need no lane parallelism and are either
+ *            input-only or deferrable:  VAD frame log-energy of the frame pushed at i-1 (consumed
+ *            by B0 two frames later), in-order sum of denSigSE1 of frame i-2 (consumed by B1),
+ *            DC-offset recurrence + int16 cast + store of frame i-4.
  *
- * with one s_barrier per frame.  FRONT halves depend only on the sample buffers; all recursive
- * state lives in the registers of waves 1 and 3.  The two 320-sample stage buffers of the
- * reference (NoiseSup.c:98-99) become 8-slot circular buffers of 80-sample frames in LDS that
- * several waves read while one writes the newest slot (slots 0..2 are mirrored behind the end so
- * that every 200- or 96-sample run is contiguous).  Small records (PSD, gain-factor energies,
- * frame validity / tick number) are handed down the pipeline through double-buffered LDS slots.
+ * FRONT halves depend only on the sample buffers; all recursive state lives in the registers of B0,
+ * B1 and S.  The two 320-sample stage buffers of the reference (NoiseSup.c:98-99) become 8-slot
+ * circular buffers of 80-sample frames in LDS that several waves read while one writes the newest
+ * slot (slots 0..2 are mirrored behind the end so that every 200- or 96-sample run is contiguous).
+ * Per-frame records travel down the pipeline through double-buffered LDS slots; values with a
+ * longer life (frame energies, denSigSE1 sums) sit in 8-entry rings indexed by tick number.
  *
  * Arithmetic is ns_core.h's, shared with the single-wave kernels: results are identical.
  */
@@ -31,29 +35,41 @@ constexpr int kSlots = 8;
 constexpr int kSlotLen = SEA_HOP;
 constexpr int kCirc = kSlots * kSlotLen;   /* 640 */
 constexpr int kMirror = 3 * kSlotLen;      /* slots 0..2 repeated behind the end */
+constexpr int kPipeWaves = 5;
 
-struct __attribute__((aligned(16))) Rec01 { /* wave 0 -> wave 1 */
+/* timing-only diagnostic: bit k set = wave k does its work (default all) */
+#ifndef SEA_ROLE_MASK
+#define SEA_ROLE_MASK 31
+#endif
+
+struct __attribute__((aligned(16))) Rec01 { /* F0 -> B0, S */
     float psd[68];
     int valid, tick, pad0, pad1;
 };
-struct __attribute__((aligned(16))) Rec12 { /* wave 1 -> wave 2 */
-    float denEn[4];
+struct __attribute__((aligned(16))) Rec12 { /* B0 -> F1, S */
+    float den[68]; /* denSigSE1 of this tick, summed in order by S */
     int valid, tick, pad0, pad1;
 };
-struct __attribute__((aligned(16))) Rec23 { /* wave 2 -> wave 3 */
+struct __attribute__((aligned(16))) Rec23 { /* F1 -> B1 */
     float psd[68];
-    float denEn[4];
     int valid, tick, pad0, pad1;
+};
+struct __attribute__((aligned(16))) Rec34 { /* B1 -> S */
+    float out[80]; /* second-stage filter output before the DC-offset filter */
+    int produced, pad0, pad1, pad2;
 };
 
 struct __attribute__((aligned(16))) PipeLds {
     float circ[2][kCirc + kMirror]; /* stage-0 / stage-1 sample buffers */
-    float work[2][256];             /* FFT workspaces of waves 0 and 2 */
-    BackLds back[2];                /* scratch of waves 1 and 3 */
-    float outb[80];                 /* wave 3: second-stage output / DC-filtered output */
+    float work[2][256];             /* FFT workspaces of F0 and F1 */
+    BackLds back[2];                /* scratch of B0 and B1 */
+    float ssq[80], sdif[80], sout[80]; /* scratch of S */
+    float frameEn[kSlots];          /* VAD log-energy for tick t at [t & 7] */
+    float denSum[kSlots];           /* sum of denSigSE1 of tick t at [t & 7] */
     Rec01 r01[2];
     Rec12 r12[2];
     Rec23 r23[2];
+    Rec34 r34[2];
 };
 
 /* start of the 320-sample window "buf[0..319]" of the reference at tick t: buf[240..319] is the
@@ -106,7 +122,7 @@ __device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables 
 
 } // namespace
 
-__global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
+__global__ __launch_bounds__(320, 5) void ns_denoise_pipe_kernel(NsBatchArgs a)
 {
     __shared__ PipeLds L;
     const int lane = threadIdx.x & 63;
@@ -114,18 +130,23 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long off = a.offsets[u];
     const long long nfr = a.lengths[u] / SEA_HOP;
-    const long long niter = nfr + 3;
+    const long long niter = nfr + 4;
 
-    for (int i = threadIdx.x; i < 2 * (kCirc + kMirror); i += 256) (&L.circ[0][0])[i] = 0.0f;
+    for (int i = threadIdx.x; i < 2 * (kCirc + kMirror); i += 64 * kPipeWaves) (&L.circ[0][0])[i] = 0.0f;
+    if (threadIdx.x < kSlots) {
+        L.frameEn[threadIdx.x] = 0.0f;
+        L.denSum[threadIdx.x] = 0.0f;
+    }
     if (threadIdx.x < 2) {
         L.r01[threadIdx.x].valid = 0;
         L.r12[threadIdx.x].valid = 0;
         L.r23[threadIdx.x].valid = 0;
+        L.r34[threadIdx.x].produced = 0;
     }
     block_sync();
 
     if (role == 0) {
-        /* ---- wave 0: input, zero-frame gate (ParmInterface.c:244-251), FRONT of stage 0 ---- */
+        /* ---- F0: input, zero-frame gate (ParmInterface.c:244-251), FRONT of stage 0 ---- */
         FrontConst C;
         load_front_const(C, a.tables, lane);
         const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in + off);
@@ -145,7 +166,7 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                     const float x0 = (float)(short)(w & 0xFFFFu), x1 = (float)(short)(w >> 16);
                     if (lane < 40) slot_store(L.circ[0], tick, lane, x0, x1);
                     wave_sync();
-                    if (tick >= 3) /* nbFramesInFirstStage - nbFramesInSecondStage > 2, NoiseSup.c:1152 */
+                    if ((SEA_ROLE_MASK & 1) && tick >= 3) /* nbFramesInFirstStage - nbFramesInSecondStage > 2, NoiseSup.c:1152 */
                         ns_front(L.circ[0] + window_base(tick), L.work[0], r.psd, C.fft, C.win, lane);
                 }
                 if (lane == 0) {
@@ -156,7 +177,7 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
             block_sync();
         }
     } else if (role == 1) {
-        /* ---- wave 1: BACK of stage 0; its 80 outputs enter the stage-1 buffer ---- */
+        /* ---- B0: BACK of stage 0; its 80 outputs enter the stage-1 buffer ---- */
         NsConst C;
         load_back_const(C, a.tables, lane);
         NsRegs s;
@@ -167,9 +188,10 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                 const Rec01 &r = L.r01[f & 1];
                 Rec12 &o = L.r12[f & 1];
                 const int valid = r.valid, t = r.tick;
-                if (valid && t >= 3) {
+                if ((SEA_ROLE_MASK & 2) && valid && t >= 3) {
                     float *tmp = L.back[0].sq; /* FIR output staged here, then stored with its mirror */
-                    ns_back<0>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane);
+                    ns_back<0, true>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
+                                     L.frameEn[t & (kSlots - 1)], o.den);
                     if (lane < 40) {
                         const float2 v = *reinterpret_cast<const float2 *>(tmp + 2 * lane);
                         slot_store(L.circ[1], t, lane, v.x, v.y);
@@ -178,15 +200,12 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                 if (lane == 0) {
                     o.valid = valid;
                     o.tick = t;
-                    o.denEn[0] = s.denEn0;
-                    o.denEn[1] = s.denEn1;
-                    o.denEn[2] = s.denEn2;
                 }
             }
             block_sync();
         }
     } else if (role == 2) {
-        /* ---- wave 2: FRONT of stage 1 (nbFramesInSecondStage - nbFramesOut > 2 <=> tick >= 5) ---- */
+        /* ---- F1: FRONT of stage 1 (nbFramesInSecondStage - nbFramesOut > 2 <=> tick >= 5) ---- */
         FrontConst C;
         load_front_const(C, a.tables, lane);
         for (long long i = 0; i < niter; ++i) {
@@ -195,62 +214,97 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                 const Rec12 &r = L.r12[f & 1];
                 Rec23 &o = L.r23[f & 1];
                 const int valid = r.valid, t = r.tick;
-                if (valid && t >= 5)
+                if ((SEA_ROLE_MASK & 4) && valid && t >= 5)
                     ns_front(L.circ[1] + window_base(t), L.work[1], o.psd, C.fft, C.win, lane);
                 if (lane == 0) {
                     o.valid = valid;
                     o.tick = t;
-                    o.denEn[0] = r.denEn[0];
-                    o.denEn[1] = r.denEn[1];
-                    o.denEn[2] = r.denEn[2];
                 }
             }
             block_sync();
         }
-    } else {
-        /* ---- wave 3: BACK of stage 1, DC-offset filter, int16 cast, store ---- */
+    } else if (role == 3) {
+        /* ---- B1: BACK of stage 1 ---- */
         NsConst C;
         load_back_const(C, a.tables, lane);
         NsRegs s;
         regs_init(s, C.eps);
-        uint32_t *out32 = reinterpret_cast<uint32_t *>(a.out + off);
-        float *outf = a.out_f32 ? a.out_f32 + off : nullptr;
-        int firstOut = -1;
         for (long long i = 0; i < niter; ++i) {
             const long long f = i - 3;
             if (f >= 0 && f < nfr) {
                 const Rec23 &r = L.r23[f & 1];
+                Rec34 &o = L.r34[f & 1];
                 const int valid = r.valid, t = r.tick;
-                bool produced = false;
-                if (valid && t >= 5) {
-                    s.denEn0 = r.denEn[0];
-                    s.denEn1 = r.denEn[1];
-                    s.denEn2 = r.denEn[2];
-                    ns_back<1>(r.psd, L.circ[1] + window_base(t), L.back[1], s, C, L.outb, lane);
-                    /* DCOffsetFil (NoiseSup.c:182-198): differences in parallel, then the recurrence */
-                    const float xm1 = (lane == 0) ? s.dcX : L.outb[lane - 1];
-                    const float d0 = L.outb[lane] - xm1;
-                    float d1 = 0.0f;
-                    if (lane < 16) d1 = L.outb[64 + lane] - L.outb[63 + lane];
-                    s.dcX = L.outb[79];
-                    wave_sync();
-                    L.back[1].sq[lane] = d0;
-                    if (lane < 16) L.back[1].sq[64 + lane] = d1;
-                    wave_sync();
-                    dc_filter(L.back[1].sq, L.outb, s.dcY, lane);
-                    produced = true;
-                    if (firstOut < 0) firstOut = (int)f;
+                int produced = 0;
+                if ((SEA_ROLE_MASK & 8) && valid && t >= 5) {
+                    /* denEn1[0..2] (NoiseSup.c:595-598) = sums of denSigSE1 of ticks t-2, t-1, t */
+                    s.denEn0 = L.denSum[(t - 2) & (kSlots - 1)];
+                    s.denEn1 = L.denSum[(t - 1) & (kSlots - 1)];
+                    s.denEn2 = L.denSum[t & (kSlots - 1)];
+                    ns_back<1, true>(r.psd, L.circ[1] + window_base(t), L.back[1], s, C, o.out, lane);
+                    produced = 1;
                 }
-                /* what etsi_denoise copies out for this frame (AdvFrontEnd.c:186-190): zeros until
-                 * the first NoiseSup output; float -> int16 is the bare cast of ParmInterface.c:266 */
+                if (lane == 0) o.produced = produced;
+            }
+            block_sync();
+        }
+    } else {
+        /* ---- S: scalar chains ---- */
+        uint32_t *out32 = reinterpret_cast<uint32_t *>(a.out + off);
+        float *outf = a.out_f32 ? a.out_f32 + off : nullptr;
+        float dcX = 0.0f, dcY = 0.0f; /* prevSamples, NoiseSup.c:908-909 */
+        int firstOut = -1;
+        for (long long i = 0; i < niter; ++i) {
+            /* (1) VAD log-energy (NoiseSup.c:386-391) of the frame pushed at i-1 = tick tp; it is
+             *     the "current frame" buf[80..159] of tick tp+2 */
+            const long long fp = i - 1;
+            if (fp >= 0 && fp < nfr) {
+                const Rec01 &r = L.r01[fp & 1];
+                if ((SEA_ROLE_MASK & 16) && r.valid) {
+                    const int tp = r.tick;
+                    const float sum = vad_frame_sum(L.circ[0] + (tp & (kSlots - 1)) * kSlotLen, L.ssq, lane);
+                    const float en = vad_frame_energy(sum);
+                    if (lane == 0) L.frameEn[(tp + 2) & (kSlots - 1)] = en;
+                }
+            }
+            /* (2) in-order sum of denSigSE1 (NoiseSup.c:597-598) of the tick B0 finished at i-1 */
+            const long long fd = i - 2;
+            if (fd >= 0 && fd < nfr) {
+                const Rec12 &r = L.r12[fd & 1];
+                if ((SEA_ROLE_MASK & 32 || SEA_ROLE_MASK == 31) && r.valid && r.tick >= 3) {
+#ifdef SEA_ABLATE_GSUM
+                    const float total = r.den[0] + r.den[64];
+#else
+                    const float total = serial_sum<65>(r.den, 0.0f);
+#endif
+                    if (lane == 0) L.denSum[r.tick & (kSlots - 1)] = total;
+                }
+            }
+            /* (3) DC-offset filter (NoiseSup.c:182-198), int16 cast (ParmInterface.c:266), store of
+             *     the frame B1 finished at i-1.  etsi_denoise copies zeros until the first NoiseSup
+             *     output (AdvFrontEnd.c:186-190). */
+            const long long fo = i - 4;
+            if (fo >= 0 && fo < nfr) {
+                const Rec34 &r = L.r34[fo & 1];
+                const bool produced = (SEA_ROLE_MASK & 64 || SEA_ROLE_MASK == 31) && r.produced != 0;
+                if (produced) {
+                    const float xm1 = (lane == 0) ? dcX : r.out[lane - 1];
+                    const float d0 = r.out[lane] - xm1;
+                    L.sdif[lane] = d0;
+                    if (lane < 16) L.sdif[64 + lane] = r.out[64 + lane] - r.out[63 + lane];
+                    dcX = r.out[79];
+                    wave_sync();
+                    dc_filter(L.sdif, L.sout, dcY, lane);
+                    if (firstOut < 0) firstOut = (int)fo;
+                }
                 if (lane < 40) {
                     uint32_t packed = 0u;
                     if (produced) {
-                        const float2 v = *reinterpret_cast<const float2 *>(&L.outb[2 * lane]);
+                        const float2 v = *reinterpret_cast<const float2 *>(&L.sout[2 * lane]);
                         packed = (uint32_t)cast_i16(v.x) | ((uint32_t)cast_i16(v.y) << 16);
-                        if (outf) *reinterpret_cast<float2 *>(outf + f * SEA_HOP + 2 * lane) = v;
+                        if (outf) *reinterpret_cast<float2 *>(outf + fo * SEA_HOP + 2 * lane) = v;
                     }
-                    out32[f * 40 + lane] = packed;
+                    out32[fo * 40 + lane] = packed;
                 }
                 wave_sync();
             }

@@ -178,7 +178,7 @@ template <int N>
 __device__ __forceinline__ float serial_sum(const float *p, float init)
 {
     float acc = init;
-#pragma unroll
+#pragma unroll 4 /* bounded: a full unroll hoists all N loads and costs N VGPRs */
     for (int i = 0; i < N / 4; ++i) {
         const float4 v = *reinterpret_cast<const float4 *>(p + 4 * i);
         acc += v.x;

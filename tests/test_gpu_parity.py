@@ -297,3 +297,22 @@ def test_selftest_dc_filter_fast_and_exact_paths():
     assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
     assert fb[2] == 1 and fb[3] == 1 and fb[1] == 0
     print("dc fallbacks:", int(fb.sum()), "of", n)
+
+
+def test_ns_pipeline_fill_and_drain(oracle):
+    """Utterances of 0..12 frames (plus ragged tails): the 5-deep wave pipeline must fill and drain
+    exactly like the serial reference (outputs start at frame 4, nothing before)."""
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    _torch()
+    utts = [corpus.synth_utterance(50 + n, 80 * n + (n * 13) % 80) for n in range(13)]
+    utts += [np.concatenate([np.zeros(80 * k, np.int16), corpus.synth_utterance(70 + k, 80 * 7)]) for k in (1, 2, 5)]
+    batch = sea.PackedBatch.from_arrays(utts)
+    out, f32, first = sea.ns_denoise_batch(batch, want_f32=True)
+    outs = batch.split(out, full_frames_only=True)
+    first = first.cpu().numpy()
+    for u, x in enumerate(utts):
+        tr = oracle.ns_trace(x, want_state=False)
+        want = tr["out_i16"][: len(x) // 80 * 80]
+        assert np.array_equal(outs[u], want), f"utt {u} (L={len(x)})"
+        assert int(first[u]) == (len(x) // 80 - tr["nout"] if tr["nout"] else -1)
