@@ -135,6 +135,8 @@ int sea_selftest_pi4(unsigned long long *n_mismatch);
 /* DC-offset recurrence on ncases frames of 80 differences (host pointers): output and whether the
  * exact double path had to be taken */
 int sea_selftest_dc(const float *dif, const float *y0, float *out, int *fellback, int ncases);
+/* the kernels' own double-precision natural log (positive normal arguments) on n floats (host pointers) */
+int sea_selftest_log(const float *x, double *ln_out, int n);
 
 #ifdef __cplusplus
 }

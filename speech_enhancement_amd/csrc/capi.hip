@@ -542,4 +542,21 @@ int sea_selftest_dc(const float *dif, const float *y0, float *out, int *fellback
     return 0;
 }
 
+int sea_selftest_log(const float *x, double *ln_out, int n)
+{
+    if (n <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    DevBuf<float> dx;
+    DevBuf<double> dout;
+    HIP_TRY(dx.alloc(n));
+    HIP_TRY(dout.alloc(n));
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sea::selftest_log_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, dx.p, dout.p, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(ln_out, dout.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 } // extern "C"

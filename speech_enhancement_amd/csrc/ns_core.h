@@ -89,6 +89,52 @@ __device__ __forceinline__ float uniform_f(float v)
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
+/* Natural logarithm of a positive, finite, normal double (the only arguments the hot path has:
+ * a float >= 64 promoted to double, and a float > 1e-5).  The reference calls libm's log()/log10()
+ * (< 1 ulp) at two scalar sites per frame and immediately rounds the result of a short double
+ * expression to float; any double log accurate to a few ulp yields the same float except when the
+ * exact value sits within ~1e-16 (relative) of a float rounding boundary (probability ~1e-8 per
+ * call) -- the same caveat the device library's own log carries against glibc.  This one is
+ * ~3x shorter than the general-purpose library routine, which matters because both sites sit on
+ * lane-redundant critical chains:  x = m 2^e, m in [sqrt(1/2), sqrt 2), f = (m-1)/(m+1),
+ * ln m = 2 f (1 + f^2/3 + f^4/5 + ... + f^22/23), ln x = e ln2_hi + (e ln2_lo + ln m).
+ * Measured against 40-digit references by tests/test_gpu_parity.py::test_selftest_log. */
+__device__ __forceinline__ double ns_ln(double x)
+{
+    const long long bits = __double_as_longlong(x);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL); /* [1,2) */
+    const bool big = m > 1.4142135623730951;
+    m = big ? m * 0.5 : m;
+    e = big ? e + 1 : e;
+    /* f = (m-1)/(m+1) by reciprocal refinement (m+1 in [1.7, 2.42]: no scaling needed) */
+    const double d = m + 1.0, n = m - 1.0;
+    double r = __builtin_amdgcn_rcp(d);
+    r = __fma_rn(__fma_rn(-d, r, 1.0), r, r);
+    r = __fma_rn(__fma_rn(-d, r, 1.0), r, r);
+    double f = n * r;
+    f = __fma_rn(__fma_rn(-d, f, n), r, f);
+    const double f2 = f * f;
+    double p = 1.0 / 23.0;
+    p = __fma_rn(p, f2, 1.0 / 21.0);
+    p = __fma_rn(p, f2, 1.0 / 19.0);
+    p = __fma_rn(p, f2, 1.0 / 17.0);
+    p = __fma_rn(p, f2, 1.0 / 15.0);
+    p = __fma_rn(p, f2, 1.0 / 13.0);
+    p = __fma_rn(p, f2, 1.0 / 11.0);
+    p = __fma_rn(p, f2, 1.0 / 9.0);
+    p = __fma_rn(p, f2, 1.0 / 7.0);
+    p = __fma_rn(p, f2, 1.0 / 5.0);
+    p = __fma_rn(p, f2, 1.0 / 3.0);
+    /* ln m = 2f + 2f * f2 * p  (the leading term kept separate: it carries almost all the value) */
+    const double two_f = f + f;
+    const double lnm = __fma_rn(two_f * f2, p, two_f);
+    const double de = (double)e;
+    /* ln2 split so that e * ln2_hi is exact for |e| < 2^10 */
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    return __fma_rn(de, ln2_hi, __fma_rn(de, ln2_lo, lnm));
+}
+
 /* One PSD bin of FilterCalc (NoiseSup.c:449-563).  P = 2-frame mean PSD, nSig = this frame's PSD.
  * nb is the frame counter narrowed to int16 as the reference does. */
 template <int ST>
@@ -133,7 +179,11 @@ __device__ __forceinline__ float filter_bin(float P, float nSig, float &noise, f
  * the raw frame only, so the pipelined kernel computes it in its helper wave */
 __device__ __forceinline__ float vad_frame_energy(float frameSum)
 {
+#ifdef SEA_LIBM_LOG
     return uniform_f((float)(0.5 + (log((double)frameSum / 64.0) / kLn2) * 16.0));
+#else
+    return uniform_f((float)(0.5 + (ns_ln((double)frameSum / 64.0) / kLn2) * 16.0));
+#endif
 }
 
 /* squares of the raw frame frame[0..79] -> sq[0..79], then the in-order sum (all lanes) */
@@ -188,7 +238,11 @@ __device__ __forceinline__ void gain_fact_update(NsRegs &s, float noiseEn)
 {
     float averSNR = (s.denEn0 * s.denEn1 * s.denEn2) / (noiseEn * noiseEn * noiseEn);
     if ((double)averSNR > 0.00001)
+#ifdef SEA_LIBM_LOG
         averSNR = (float)((20 * log10((double)averSNR)) / 3.0);
+#else /* log10(y) = ln(y) * log10(e) */
+        averSNR = (float)((20 * (ns_ln((double)averSNR) * 0.43429448190325182765)) / 3.0);
+#endif
     else
         averSNR = (float)(-100.0 / 3.0);
     averSNR = uniform_f(averSNR);
@@ -249,7 +303,7 @@ __device__ __forceinline__ void ns_front(const float *buf, float *work, float *p
 template <int ST, bool PIPE>
 __device__ __forceinline__ void ns_back(const float *psd, const float *buf, BackLds &B, NsRegs &s,
                                         const NsConst &C, float *dst, int lane, float frameEnExt = 0.0f,
-                                        float *spectOut = nullptr)
+                                        float *spectOut = nullptr, const float *idctLds = nullptr)
 {
     const float nSigLo = psd[lane], nSigHi = psd[64];
 
@@ -324,14 +378,15 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     if (lane <= 8) {
         float h = 0.0f;
 #pragma unroll
+        /* PIPE: the 9x25 basis sits in LDS ([f][16], lane = row) instead of 25 VGPRs per lane */
         for (int f4 = 0; f4 < 24; f4 += 4) {
             const float4 m = *reinterpret_cast<const float4 *>(&B.mel[f4]);
-            h += m.x * C.idct[f4];
-            h += m.y * C.idct[f4 + 1];
-            h += m.z * C.idct[f4 + 2];
-            h += m.w * C.idct[f4 + 3];
+            h += m.x * (PIPE ? idctLds[(f4 + 0) * 16 + lane] : C.idct[f4]);
+            h += m.y * (PIPE ? idctLds[(f4 + 1) * 16 + lane] : C.idct[f4 + 1]);
+            h += m.z * (PIPE ? idctLds[(f4 + 2) * 16 + lane] : C.idct[f4 + 2]);
+            h += m.w * (PIPE ? idctLds[(f4 + 3) * 16 + lane] : C.idct[f4 + 3]);
         }
-        h += B.mel[24] * C.idct[24];
+        h += B.mel[24] * (PIPE ? idctLds[24 * 16 + lane] : C.idct[24]);
         const float tap = h * C.irWin;
         B.fir[8 + lane] = tap;
         B.fir[8 - lane] = tap;

@@ -135,4 +135,11 @@ __global__ __launch_bounds__(64) void selftest_dc_kernel(const float *dif, const
     }
 }
 
+/* the hot path's own natural log (ns_core.h) on n floats promoted to double */
+__global__ __launch_bounds__(256) void selftest_log_kernel(const float *x, double *out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ns_ln((double)x[i]);
+}
+
 } // namespace sea

@@ -66,6 +66,7 @@ struct __attribute__((aligned(16))) PipeLds {
     float ssq[80], sdif[80], sout[80]; /* scratch of S */
     float frameEn[kSlots];          /* VAD log-energy for tick t at [t & 7] */
     float denSum[kSlots];           /* sum of denSigSE1 of tick t at [t & 7] */
+    float idctT[SEA_NMEL * 16];     /* mel-IDCT basis rows 0..8: [f][16], shared by B0 and B1 */
     Rec01 r01[2];
     Rec12 r12[2];
     Rec23 r23[2];
@@ -114,8 +115,6 @@ __device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables 
     C.melLen = t->melLen[lane];
 #pragma unroll
     for (int i = 0; i < SEA_MEL_TAPS; ++i) C.melW[i] = t->melW[i][lane];
-#pragma unroll
-    for (int f = 0; f < SEA_NMEL; ++f) C.idct[f] = t->idct[f][lane];
     C.irWin = t->irWin[lane];
     C.eps = t->eps;
 }
@@ -133,6 +132,7 @@ __global__ __launch_bounds__(320, 5) void ns_denoise_pipe_kernel(NsBatchArgs a)
     const long long niter = nfr + 4;
 
     for (int i = threadIdx.x; i < 2 * (kCirc + kMirror); i += 64 * kPipeWaves) (&L.circ[0][0])[i] = 0.0f;
+    for (int i = threadIdx.x; i < SEA_NMEL * 16; i += 64 * kPipeWaves) L.idctT[i] = a.tables->idct[i >> 4][i & 15];
     if (threadIdx.x < kSlots) {
         L.frameEn[threadIdx.x] = 0.0f;
         L.denSum[threadIdx.x] = 0.0f;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(320, 5) void ns_denoise_pipe_kernel(NsBatchArgs a)
                 if ((SEA_ROLE_MASK & 2) && valid && t >= 3) {
                     float *tmp = L.back[0].sq; /* FIR output staged here, then stored with its mirror */
                     ns_back<0, true>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
-                                     L.frameEn[t & (kSlots - 1)], o.den);
+                                     L.frameEn[t & (kSlots - 1)], o.den, L.idctT);
                     if (lane < 40) {
                         const float2 v = *reinterpret_cast<const float2 *>(tmp + 2 * lane);
                         slot_store(L.circ[1], t, lane, v.x, v.y);
@@ -241,7 +241,8 @@ __global__ __launch_bounds__(320, 5) void ns_denoise_pipe_kernel(NsBatchArgs a)
                     s.denEn0 = L.denSum[(t - 2) & (kSlots - 1)];
                     s.denEn1 = L.denSum[(t - 1) & (kSlots - 1)];
                     s.denEn2 = L.denSum[t & (kSlots - 1)];
-                    ns_back<1, true>(r.psd, L.circ[1] + window_base(t), L.back[1], s, C, o.out, lane);
+                    ns_back<1, true>(r.psd, L.circ[1] + window_base(t), L.back[1], s, C, o.out, lane, 0.0f, nullptr,
+                                     L.idctT);
                     produced = 1;
                 }
                 if (lane == 0) o.produced = produced;

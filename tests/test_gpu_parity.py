@@ -316,3 +316,52 @@ def test_ns_pipeline_fill_and_drain(oracle):
         want = tr["out_i16"][: len(x) // 80 * 80]
         assert np.array_equal(outs[u], want), f"utt {u} (L={len(x)})"
         assert int(first[u]) == (len(x) // 80 - tr["nout"] if tr["nout"] else -1)
+
+
+def test_selftest_log_accuracy():
+    """The kernels' own double log (two scalar sites per frame) against 40-digit references: within
+    2 ulp, and the two float results the hot path derives from it equal the ones libm's log gives on
+    every sampled argument."""
+    import math
+    from decimal import Decimal, getcontext
+    import speech_enhancement_amd as sea
+    _torch()
+    getcontext().prec = 40
+    rng = np.random.default_rng(11)
+    x = np.concatenate([
+        np.float32(64.0) + rng.uniform(0, 1, 4000).astype(np.float32) * np.float32(2.0) ** rng.integers(0, 36, 4000),
+        (10.0 ** rng.uniform(-5, 12, 4000)).astype(np.float32),
+        np.array([64.0, 1.0, 2.0, 0.5, 1.4142135, 1.4142137, 1e-5, 3.4e38, 1.1754944e-38], np.float32)])
+    x = x.astype(np.float32)
+    out = np.zeros(x.size, np.float64)
+    assert sea.load().sea_selftest_log(x.ctypes.data, out.ctypes.data, x.size) == 0
+    worst = 0.0
+    for xi, yi in zip(x[::7], out[::7]):
+        true = Decimal(float(xi)).ln()
+        ulp = Decimal(math.ulp(float(true))) if true != 0 else Decimal(5e-324)
+        worst = max(worst, float(abs(Decimal(float(yi)) - true) / ulp))
+    print("ns_ln worst error (ulp):", worst)
+    assert worst <= 2.0
+    # the derived floats of the two call sites (NoiseSup.c:391 and :607)
+    big = x[x >= 64.0]
+    ref = np.array([np.float32(0.5 + (math.log(float(v) / 64.0) / math.log(2.0)) * 16.0) for v in big])
+    mine = np.array([np.float32(0.5 + (float(o) / math.log(2.0)) * 16.0) for o in _ln_ratio(big)])
+    print("VAD-energy site float mismatches:", int(np.sum(mine != ref)), "of", ref.size)
+    assert np.mean(mine == ref) >= 0.9999
+    small = x > 1e-5
+    a = np.array([np.float32((20 * (o * 0.43429448190325182765)) / 3.0) for o in out[small]])
+    b = np.array([np.float32((20 * math.log10(float(v))) / 3.0) for v in x[small]])
+    print("log10 site float mismatches:", int(np.sum(a != b)), "of", a.size)
+    assert np.mean(a == b) >= 0.9999
+
+
+def _ln_ratio(x):
+    """ln(x/64) from the device's ln: the kernel evaluates ns_ln on x/64 directly; the division by
+    64 is exact, so recompute on the host the same way through the selftest entry point."""
+    import speech_enhancement_amd as sea
+    q = (x.astype(np.float64) / 64.0)
+    q32 = q.astype(np.float32)
+    assert np.array_equal(q32.astype(np.float64), q)  # exact: power-of-two scaling of a float
+    out = np.zeros(q32.size, np.float64)
+    assert sea.load().sea_selftest_log(q32.ctypes.data, out.ctypes.data, q32.size) == 0
+    return out
