@@ -153,7 +153,7 @@ int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
     if (single)
         hipLaunchKernelGGL(sea::ns_denoise_kernel, dim3(n_utt), dim3(64), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(sea::ns_denoise_pipe_kernel, dim3(n_utt), dim3(320), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(sea::ns_denoise_pipe_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -292,6 +292,42 @@ __device__ __forceinline__ void ns_front(const float *buf, float *work, float *p
     wave_sync();
 }
 
+/* FFTtoPSD (NoiseSup.c:249-270) of one transformed frame in work[0..255] -> psd[0..64] */
+__device__ __forceinline__ void psd_from_fft(const float *work, float *psd, int lane)
+{
+    const float re0 = work[2 * lane], re1 = work[2 * lane + 1];
+    const float im1 = work[255 - 2 * lane];
+    const float im0 = (lane > 0) ? work[256 - 2 * lane] : 0.0f;
+    const float p0 = (lane > 0) ? (re0 * re0 + im0 * im0) : (re0 * re0);
+    const float p1 = re1 * re1 + im1 * im1;
+    psd[lane] = (p0 + p1) * 0.5f;
+    if (lane == 0) {
+        const float ny = work[128];
+        psd[64] = ny * ny;
+    }
+}
+
+/* Two FRONT halves in one wave: frame A (stage buffer bufA) and frame B (bufB) are windowed,
+ * transformed side by side (rfft256_dual) and reduced to their 65-bin PSDs.  actA / actB are
+ * wave-uniform; an inactive side is fed zeros and its PSD is not written.  work: 512 floats. */
+__device__ __forceinline__ void ns_front_dual(const float *bufA, bool actA, float *psdA, const float *bufB,
+                                              bool actB, float *psdB, float *work, const Fft2Regs &fft,
+                                              unsigned flags, const float (&win)[4], int lane)
+{
+    float eA[4], eB[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int idx = 60 + lane + 64 * k;
+        const bool in = (k < 3) || (lane < 8);
+        eA[k] = (actA && in) ? bufA[idx] * win[k] : 0.0f;
+        eB[k] = (actB && in) ? bufB[idx] * win[k] : 0.0f;
+    }
+    rfft256_dual(eA, eB, work, fft, flags, lane);
+    if (actA) psd_from_fft(work, psdA, lane);
+    if (actB) psd_from_fft(work + 256, psdB, lane);
+    wave_sync();
+}
+
 /* BACK half of a stage (ST = 0 first, 1 second): everything recursive.  Consumes psd[0..64] and
  * the stage buffer (raw frame buf[80..159] for the VAD, buf[72..167] for the FIR), updates the
  * per-utterance state and deposits the 80 filtered samples in dst.  Ends with wave_sync().

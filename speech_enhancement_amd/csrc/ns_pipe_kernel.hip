@@ -1,22 +1,23 @@
 /*
- * ns_pipe_kernel.hip -- etsi_denoise over a packed batch, FIVE PIPELINED WAVEFRONTS per utterance.
+ * ns_pipe_kernel.hip -- etsi_denoise over a packed batch, FOUR PIPELINED WAVEFRONTS per utterance.
  *
  * Frames of one utterance are serially dependent, so a batch of N utterances offers
  * only N independent chains: at BASELINE configs[1] (1024 utterances on 1024 SIMDs) a
  * one-wave-per-utterance kernel leaves every SIMD with a single latency-bound wave.  The frame
  * recursion however is a software pipeline, and this kernel gives each depth its own wave
- * (workgroup = 320 threads = one utterance), one s_barrier per frame:
+ * (workgroup = 256 threads = one utterance, one wave per SIMD of a CU), one s_barrier per frame:
  *
- *   wave F0  frame i     load int16, zero-frame gate, push into stage-0 buffer, window+rfft+PSD
+ *   wave F   iteration i: load int16 frame i, zero-frame gate, push into the stage-0 buffer; then
+ *            BOTH front halves side by side in one dual transform (lanes 0..31 / 32..63):
+ *            window+rfft+PSD of stage 0 for frame i and of stage 1 for frame i-2
  *   wave B0  frame i-1   stage-0 FilterCalc, mel, IDCT, 17-tap FIR  -> stage-1 buffer
- *   wave F1  frame i-2   window+rfft+PSD of the stage-1 buffer
  *   wave B1  frame i-3   stage-1 FilterCalc, gain factorisation, mel, IDCT, FIR
  *   wave S   the lane-redundant scalar chains that need no lane parallelism and are either
  *            input-only or deferrable:  VAD frame log-energy of the frame pushed at i-1 (consumed
  *            by B0 two frames later), in-order sum of denSigSE1 of frame i-2 (consumed by B1),
  *            DC-offset recurrence + int16 cast + store of frame i-4.
  *
- * FRONT halves depend only on the sample buffers; all recursive state lives in the registers of B0,
+ * Front halves depend only on the sample buffers; all recursive state lives in the registers of B0,
  * B1 and S.  The two 320-sample stage buffers of the reference (NoiseSup.c:98-99) become 8-slot
  * circular buffers of 80-sample frames in LDS that several waves read while one writes the newest
  * slot (slots 0..2 are mirrored behind the end so that every 200- or 96-sample run is contiguous).
@@ -35,22 +36,22 @@ constexpr int kSlots = 8;
 constexpr int kSlotLen = SEA_HOP;
 constexpr int kCirc = kSlots * kSlotLen;   /* 640 */
 constexpr int kMirror = 3 * kSlotLen;      /* slots 0..2 repeated behind the end */
-constexpr int kPipeWaves = 5;
+constexpr int kPipeWaves = 4;
 
-/* timing-only diagnostic: bit k set = wave k does its work (default all) */
+/* timing-only diagnostic: bit set = that piece of work is done (default all) */
 #ifndef SEA_ROLE_MASK
-#define SEA_ROLE_MASK 31
+#define SEA_ROLE_MASK 127
 #endif
 
-struct __attribute__((aligned(16))) Rec01 { /* F0 -> B0, S */
+struct __attribute__((aligned(16))) Rec01 { /* F -> B0, S */
     float psd[68];
     int valid, tick, pad0, pad1;
 };
-struct __attribute__((aligned(16))) Rec12 { /* B0 -> F1, S */
+struct __attribute__((aligned(16))) Rec12 { /* B0 -> F, S */
     float den[68]; /* denSigSE1 of this tick, summed in order by S */
     int valid, tick, pad0, pad1;
 };
-struct __attribute__((aligned(16))) Rec23 { /* F1 -> B1 */
+struct __attribute__((aligned(16))) Rec23 { /* F -> B1 */
     float psd[68];
     int valid, tick, pad0, pad1;
 };
@@ -61,7 +62,7 @@ struct __attribute__((aligned(16))) Rec34 { /* B1 -> S */
 
 struct __attribute__((aligned(16))) PipeLds {
     float circ[2][kCirc + kMirror]; /* stage-0 / stage-1 sample buffers */
-    float work[2][256];             /* FFT workspaces of F0 and F1 */
+    float work[512];                /* the two FFT frames of F */
     BackLds back[2];                /* scratch of B0 and B1 */
     float ssq[80], sdif[80], sout[80]; /* scratch of S */
     float frameEn[kSlots];          /* VAD log-energy for tick t at [t & 7] */
@@ -95,20 +96,8 @@ __device__ __forceinline__ void block_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-/* constants a FRONT wave keeps in registers / a BACK wave keeps in registers (each wave loads only
- * its own: the role branches below have separate loops so that register allocation is per role) */
-struct FrontConst {
-    FftRegs fft;
-    float win[4];
-};
-
-__device__ __forceinline__ void load_front_const(FrontConst &C, const sea_ns_tables *t, int lane)
-{
-    load_fft_regs(C.fft, &t->fft, lane);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) C.win[k] = t->win[k][lane];
-}
-
+/* constants a BACK wave keeps in registers (each wave loads only its own: the role branches below
+ * have separate loops so that register allocation is per role) */
 __device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables *t, int lane)
 {
     C.melStart = t->melStart[lane];
@@ -121,7 +110,7 @@ __device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables 
 
 } // namespace
 
-__global__ __launch_bounds__(320, 5) void ns_denoise_pipe_kernel(NsBatchArgs a)
+__global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
 {
     __shared__ PipeLds L;
     const int lane = threadIdx.x & 63;
@@ -146,18 +135,23 @@ __global__ __launch_bounds__(320, 5) void ns_denoise_pipe_kernel(NsBatchArgs a)
     block_sync();
 
     if (role == 0) {
-        /* ---- F0: input, zero-frame gate (ParmInterface.c:244-251), FRONT of stage 0 ---- */
-        FrontConst C;
-        load_front_const(C, a.tables, lane);
+        /* ---- F: input + zero-frame gate (ParmInterface.c:244-251); front halves of both stages ---- */
+        Fft2Regs fft;
+        load_fft2_regs(fft, &a.tables->fft, lane);
+        const unsigned flags = a.tables->fft.fftFlags[lane];
+        float win[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) win[k] = a.tables->win[k][lane];
         const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in + off);
         uint32_t nextw = (lane < 40 && nfr > 0) ? in32[lane] : 0u;
         int tick = 0; /* frames seen since (and including) the first non-zero one */
         for (long long i = 0; i < niter; ++i) {
-            const long long f = i;
-            if (f < nfr) {
-                Rec01 &r = L.r01[f & 1];
+            /* stage 0, frame i */
+            bool actA = false;
+            Rec01 &rA = L.r01[i & 1];
+            if (i < nfr) {
                 const uint32_t w = nextw;
-                if (f + 1 < nfr && lane < 40) nextw = in32[(f + 1) * 40 + lane];
+                if (i + 1 < nfr && lane < 40) nextw = in32[(i + 1) * 40 + lane];
                 const bool any = __ballot(w != 0u) != 0ull;
                 int valid = 0;
                 if (any || tick > 0) {
@@ -165,14 +159,33 @@ __global__ __launch_bounds__(320, 5) void ns_denoise_pipe_kernel(NsBatchArgs a)
                     tick++;
                     const float x0 = (float)(short)(w & 0xFFFFu), x1 = (float)(short)(w >> 16);
                     if (lane < 40) slot_store(L.circ[0], tick, lane, x0, x1);
-                    wave_sync();
-                    if ((SEA_ROLE_MASK & 1) && tick >= 3) /* nbFramesInFirstStage - nbFramesInSecondStage > 2, NoiseSup.c:1152 */
-                        ns_front(L.circ[0] + window_base(tick), L.work[0], r.psd, C.fft, C.win, lane);
+                    /* nbFramesInFirstStage - nbFramesInSecondStage > 2 (NoiseSup.c:1152) <=> tick >= 3 */
+                    actA = (SEA_ROLE_MASK & 1) && tick >= 3;
                 }
                 if (lane == 0) {
-                    r.valid = valid;
-                    r.tick = tick;
+                    rA.valid = valid;
+                    rA.tick = tick;
                 }
+            }
+            /* stage 1, frame i-2: nbFramesInSecondStage - nbFramesOut > 2 (NoiseSup.c:1178) <=> tick >= 5 */
+            const long long fB = i - 2;
+            bool actB = false;
+            int tB = 0;
+            Rec23 &rB = L.r23[fB & 1];
+            if (fB >= 0 && fB < nfr) {
+                const Rec12 &r = L.r12[fB & 1];
+                const int valid = r.valid;
+                tB = r.tick;
+                actB = (SEA_ROLE_MASK & 1) && valid && tB >= 5;
+                if (lane == 0) {
+                    rB.valid = valid;
+                    rB.tick = tB;
+                }
+            }
+            if (actA || actB) {
+                wave_sync();
+                ns_front_dual(L.circ[0] + window_base(tick), actA, rA.psd, L.circ[1] + window_base(tB), actB, rB.psd,
+                              L.work, fft, flags, win, lane);
             }
             block_sync();
         }
@@ -205,25 +218,6 @@ __global__ __launch_bounds__(320, 5) void ns_denoise_pipe_kernel(NsBatchArgs a)
             block_sync();
         }
     } else if (role == 2) {
-        /* ---- F1: FRONT of stage 1 (nbFramesInSecondStage - nbFramesOut > 2 <=> tick >= 5) ---- */
-        FrontConst C;
-        load_front_const(C, a.tables, lane);
-        for (long long i = 0; i < niter; ++i) {
-            const long long f = i - 2;
-            if (f >= 0 && f < nfr) {
-                const Rec12 &r = L.r12[f & 1];
-                Rec23 &o = L.r23[f & 1];
-                const int valid = r.valid, t = r.tick;
-                if ((SEA_ROLE_MASK & 4) && valid && t >= 5)
-                    ns_front(L.circ[1] + window_base(t), L.work[1], o.psd, C.fft, C.win, lane);
-                if (lane == 0) {
-                    o.valid = valid;
-                    o.tick = t;
-                }
-            }
-            block_sync();
-        }
-    } else if (role == 3) {
         /* ---- B1: BACK of stage 1 ---- */
         NsConst C;
         load_back_const(C, a.tables, lane);
@@ -272,7 +266,7 @@ __global__ __launch_bounds__(320, 5) void ns_denoise_pipe_kernel(NsBatchArgs a)
             const long long fd = i - 2;
             if (fd >= 0 && fd < nfr) {
                 const Rec12 &r = L.r12[fd & 1];
-                if ((SEA_ROLE_MASK & 32 || SEA_ROLE_MASK == 31) && r.valid && r.tick >= 3) {
+                if ((SEA_ROLE_MASK & 32) && r.valid && r.tick >= 3) {
 #ifdef SEA_ABLATE_GSUM
                     const float total = r.den[0] + r.den[64];
 #else
@@ -287,7 +281,7 @@ __global__ __launch_bounds__(320, 5) void ns_denoise_pipe_kernel(NsBatchArgs a)
             const long long fo = i - 4;
             if (fo >= 0 && fo < nfr) {
                 const Rec34 &r = L.r34[fo & 1];
-                const bool produced = (SEA_ROLE_MASK & 64 || SEA_ROLE_MASK == 31) && r.produced != 0;
+                const bool produced = (SEA_ROLE_MASK & 64) && r.produced != 0;
                 if (produced) {
                     const float xm1 = (lane == 0) ? dcX : r.out[lane - 1];
                     const float d0 = r.out[lane] - xm1;

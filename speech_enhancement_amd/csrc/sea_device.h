@@ -163,6 +163,129 @@ __device__ __forceinline__ void rfft256(float e0, float e1, float e2, float e3, 
 #endif
 }
 
+/* ---- two independent 256-point transforms side by side in one wave (lanes 0..31 / 32..63) ----
+ * Same butterflies, same arithmetic; the plain and pi/4 butterflies of a block share one work item
+ * (SEA_BF_PAIR) so that no level needs more than 32 lanes per transform.  work holds the two
+ * frames back to back: transform A in work[0..255], B in work[256..511]. */
+struct Fft2Regs {
+    unsigned item[SEA_FFT_LSTAGES]; /* kind<<24 | b<<12 | a, a/b already offset by 256 for lanes >= 32 */
+    float tw[SEA_FFT_LSTAGES][4];
+};
+
+__device__ __forceinline__ void load_fft2_regs(Fft2Regs &R, const sea_fft_tables *t, int lane)
+{
+    const int j = lane & 31;
+    const unsigned half = (lane >> 5) * 256u;
+#pragma unroll
+    for (int s = 0; s < SEA_FFT_LSTAGES; ++s) {
+        const unsigned it = t->fft2Item[s][j];
+        const unsigned kind = it >> 16, a = (it & 255u) + half, b = ((it >> 8) & 255u) + half;
+        R.item[s] = (kind << 24) | (b << 12) | a;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) R.tw[s][k] = t->fft2Tw[s][k][j];
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void fft2_level(float *work, const Fft2Regs &R)
+{
+    constexpr int n4 = 2 << S;
+    const unsigned it = R.item[S];
+    const unsigned kind = it >> 24;
+    const int a = (int)(it & 4095u), b = (int)((it >> 12) & 4095u);
+    const float x1 = work[a], x2 = work[a + n4], x3 = work[a + 2 * n4], x4 = work[a + 3 * n4];
+    const float x5 = work[b], x6 = work[b + n4], x7 = work[b + 2 * n4], x8 = work[b + 3 * n4];
+    float o1, o2, o3, o4, o5, o6, o7, o8;
+    if (kind == SEA_BF_TWIDDLE) { /* rfft.c:145-174 */
+        const float cc1 = R.tw[S][0], ss1 = R.tw[S][1], cc3 = R.tw[S][2], ss3 = R.tw[S][3];
+        float t1 = x3 * cc1 + x7 * ss1;
+        float t2 = x7 * cc1 - x3 * ss1;
+        float t3 = x4 * cc3 + x8 * ss3;
+        float t4 = x8 * cc3 - x4 * ss3;
+        const float t5 = t1 + t3, t6 = t2 + t4;
+        t3 = t1 - t3;
+        t4 = t2 - t4;
+        o3 = t6 - x6;
+        o8 = x6 + t6;
+        o7 = -x2 - t3;
+        o4 = x2 - t3;
+        o6 = x1 - t5;
+        o1 = x1 + t5;
+        o5 = x5 - t4;
+        o2 = x5 + t4;
+    } else { /* SEA_BF_PAIR: plain butterfly on the a-quadruple (rfft.c:110-113), pi/4 butterfly on
+                the b-quadruple (rfft.c:120-125; the exact multiply form proven in fft_level) */
+        const float t1 = x4 + x3;
+        o4 = x4 - x3;
+        o3 = x1 - t1;
+        o1 = x1 + t1;
+        o2 = x2;
+        const float u1 = (float)((double)(x7 + x8) * 0.70710678118654752440);
+        const float u2 = (float)((double)(x7 - x8) * 0.70710678118654752440);
+        o8 = x6 - u1;
+        o7 = -x6 - u1;
+        o6 = x5 - u2;
+        o5 = x5 + u2;
+    }
+    if (kind != SEA_BF_NONE) {
+        work[a] = o1;
+        work[a + n4] = o2;
+        work[a + 2 * n4] = o3;
+        work[a + 3 * n4] = o4;
+        work[b] = o5;
+        work[b + n4] = o6;
+        work[b + 2 * n4] = o7;
+        work[b + 3 * n4] = o8;
+    }
+}
+
+/* the register-resident start of rfft256 (bit reversal, length-2 and n2=4 butterflies) for one
+ * frame; stores the lane's four values at work[4r..4r+3] */
+__device__ __forceinline__ void rfft256_head(float e0, float e1, float e2, float e3, float *work,
+                                             unsigned flags, int lane)
+{
+    float g0 = e0, g1 = e2, g2 = e1, g3 = e3;
+    {
+        const float s01 = g0 + g1, d01 = g0 - g1, s23 = g2 + g3, d23 = g2 - g3;
+        const bool f0 = (flags & 1u) != 0, f1 = (flags & 2u) != 0;
+        g0 = f0 ? s01 : g0;
+        g1 = f0 ? d01 : g1;
+        g2 = f1 ? s23 : g2;
+        g3 = f1 ? d23 : g3;
+    }
+    {
+        const float t1 = g3 + g2;
+        const float n3 = g3 - g2, n2 = g0 - t1, n0 = g0 + t1;
+        const bool f = (flags & 4u) != 0;
+        g3 = f ? n3 : g3;
+        g2 = f ? n2 : g2;
+        g0 = f ? n0 : g0;
+    }
+    const int r = (int)(__brev((unsigned)lane) >> 26);
+    *reinterpret_cast<float4 *>(work + 4 * r) = make_float4(g0, g1, g2, g3);
+}
+
+/* two transforms at once: eA / eB hold the lane's four (windowed) elements of frame A / B */
+__device__ __forceinline__ void rfft256_dual(const float (&eA)[4], const float (&eB)[4], float *work,
+                                             const Fft2Regs &R, unsigned flags, int lane)
+{
+    rfft256_head(eA[0], eA[1], eA[2], eA[3], work, flags, lane);
+    rfft256_head(eB[0], eB[1], eB[2], eB[3], work + 256, flags, lane);
+    wave_sync();
+    fft2_level<0>(work, R);
+    wave_sync();
+    fft2_level<1>(work, R);
+    wave_sync();
+    fft2_level<2>(work, R);
+    wave_sync();
+    fft2_level<3>(work, R);
+    wave_sync();
+    fft2_level<4>(work, R);
+    wave_sync();
+    fft2_level<5>(work, R);
+    wave_sync();
+}
+
 /* float -> int16 exactly as the reference's (short) cast behaves on x86-64: truncate toward zero
  * to int32 and keep the low 16 bits; out-of-int32-range gives 0 (etsi/cpp/ParmInterface.c:266). */
 __device__ __forceinline__ int cast_i16(float v)

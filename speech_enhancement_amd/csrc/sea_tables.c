@@ -99,6 +99,27 @@ static void build_fft(sea_fft_tables *f)
             f->fftItem[s][slot] = ((unsigned)SEA_BF_PI4 << 16) | (i1 << 8) | i1;
         }
         if (slot > SEA_LANES) abort();
+        /* half-wave packing: twiddle items, then one PAIR item (plain + pi/4) per block */
+        slot = 0;
+        for (j = 1; j < n8; j++) {
+            float a = j * e, a3 = 3 * a;
+            float cc1 = (float)cos((double)a), ss1 = (float)sin((double)a);
+            float cc3 = (float)cos((double)a3), ss3 = (float)sin((double)a3);
+            for (b = 0; b < blocks.n; b++, slot++) {
+                unsigned i1 = (unsigned)(blocks.base[b] + j), i5 = (unsigned)(blocks.base[b] + n4 - j);
+                if (slot >= 32) abort();
+                f->fft2Item[s][slot] = ((unsigned)SEA_BF_TWIDDLE << 16) | (i5 << 8) | i1;
+                f->fft2Tw[s][0][slot] = cc1;
+                f->fft2Tw[s][1][slot] = ss1;
+                f->fft2Tw[s][2][slot] = cc3;
+                f->fft2Tw[s][3][slot] = ss3;
+            }
+        }
+        for (b = 0; b < blocks.n; b++, slot++) {
+            unsigned i1 = (unsigned)blocks.base[b], ip = (unsigned)(blocks.base[b] + n8);
+            if (slot >= 32) abort();
+            f->fft2Item[s][slot] = ((unsigned)SEA_BF_PAIR << 16) | (ip << 8) | i1;
+        }
     }
 }
 

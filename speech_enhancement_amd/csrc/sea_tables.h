@@ -39,7 +39,15 @@ typedef struct {
                                                      (4r+2,4r+3); bit2: n2=4 plain bf on group */
     unsigned fftItem[SEA_FFT_LSTAGES][SEA_LANES]; /* kind<<16 | b<<8 | a  (a=i1, b=i5) */
     float fftTw[SEA_FFT_LSTAGES][4][SEA_LANES];   /* cc1, ss1, cc3, ss3 of twiddle items */
+    /* The same schedule packed into HALF a wavefront, for kernels that run two independent
+     * transforms side by side (lanes 0..31 / 32..63): the plain and pi/4 butterflies of one block
+     * are merged into one work item (kind SEA_BF_PAIR: a = plain base, b = pi/4 base), which
+     * brings every level to at most 32 items. */
+    unsigned fft2Item[SEA_FFT_LSTAGES][32];
+    float fft2Tw[SEA_FFT_LSTAGES][4][32];
 } sea_fft_tables;
+
+enum { SEA_BF_PAIR = 4 };
 
 typedef struct {
     sea_fft_tables fft;

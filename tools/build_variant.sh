@@ -8,7 +8,7 @@ C=$ROOT/speech_enhancement_amd/csrc
 name=$1; src=$2; shift 2
 mkdir -p $ROOT/ablate
 base=$(basename $src .hip)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -fno-gpu-flush-denormals-to-zero \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize \
     -I$C "$@" -c $src -o /tmp/variant_$name.o
 objs=""
 for o in capi ns_kernel ns_pipe_kernel cc_kernel resynth_kernel; do
