@@ -194,7 +194,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "sea::ns_denoise_kernel",
+                "kernel": "sea::ns_denoise_kernel" if os.environ.get("SEA_NS_KERNEL") == "single"
+                          else "sea::ns_denoise_pipe_kernel",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

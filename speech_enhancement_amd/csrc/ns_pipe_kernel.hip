@@ -88,12 +88,14 @@ __device__ __forceinline__ void slot_store(float *circ, int tick, int lane, floa
 }
 
 /* workgroup barrier usable from role-specialised (wave-uniform) branches: every wave executes the
- * same NUMBER of barriers per frame, at different program counters */
+ * same NUMBER of barriers per frame, at different program counters.  The fences cover LDS only
+ * (everything the waves exchange lives there), so global prefetches and stores stay in flight
+ * across the barrier instead of being drained (vmcnt(0)) once per frame. */
 __device__ __forceinline__ void block_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 /* constants a BACK wave keeps in registers (each wave loads only its own: the role branches below

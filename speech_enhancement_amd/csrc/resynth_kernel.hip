@@ -1,8 +1,11 @@
 /*
  * resynth_kernel.hip -- Hu-Wang 64-channel gammatone analysis/synthesis resynthesis, gfx950.
  *
- * One 64-lane wavefront owns one utterance; LANE = CHANNEL (64 channels = one wave), so the
- * 4th-order complex one-pole cascade of every channel advances one sample per step in lock-step.
+ * One workgroup (two 64-lane wavefronts) owns one utterance; LANE = CHANNEL (64 channels = one
+ * wave), so the 4th-order complex one-pole cascade of every channel advances one sample per step in
+ * lock-step.  The serial recurrence has a wave to itself; everything that is per-sample but not
+ * recursive (divisions, overlap-add weights, channel sums, stores) runs one 16-step tile behind in a
+ * helper wave.
  *
  *   resynth_fwd_kernel : analysis pass.  g1[n][c] written to HBM as rows of 64 floats (256 B per
  *                        step, fully coalesced).  288 GB of HBM is what makes keeping the whole
@@ -49,31 +52,67 @@ __device__ __forceinline__ float gt_step(GtState &s, float in, float f1, float f
     return out;
 }
 
-constexpr int kTileStride = 65; /* 64 channels + 1 pad: conflict-free row reads by lane = sample */
+constexpr int kTile = 16;        /* time steps handed from the recurrence wave to the helper wave at once */
+constexpr int kTileStride = 65;  /* 64 channels + 1 pad: conflict-free row reads by lane = sample */
+
+/* workgroup barrier for the two role-specialised waves (same count, different program counters);
+ * LDS-only fences: HBM loads and stores stay in flight across it */
+__device__ __forceinline__ void pair_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 } // namespace
 
-__global__ __launch_bounds__(64) void resynth_fwd_kernel(ResynthArgs a)
+/* Analysis pass.  Workgroup = one utterance = two waves, lane = channel in both:
+ *   wave A  the serial 4-stage recurrence (extractwav.cpp:188-210), 16 steps per tile into LDS
+ *   wave B  takes the previous tile, divides by the middle-ear gain (the "reverse[...] = gOut/midEar"
+ *           of extractwav.cpp:86-87 -- a per-sample operation that does not belong on the
+ *           recurrence's critical chain) and streams rows of 64 floats to HBM (256 B per step).
+ * The intermediate therefore holds g1[n][c] / midEar[c] in natural time order. */
+__global__ __launch_bounds__(128) void resynth_fwd_kernel(ResynthArgs a)
 {
-    __shared__ float xs[64];
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float gbuf[2][kTile][64];
+    __shared__ __attribute__((aligned(16))) float xs[kTile];
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long off = a.offsets[u], L = a.lengths[u];
-    const int16_t *in = a.in + off;
-    float *g1 = a.inter + off * 64;
-    const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane], gain = a.tables->gain[lane];
-    GtState s = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    for (long long n0 = 0; n0 < L; n0 += 64) {
-        const int cnt = (L - n0 < 64) ? (int)(L - n0) : 64;
-        wave_sync();
-        xs[lane] = (lane < cnt) ? (float)in[n0 + lane] : 0.0f; /* extractwav.cpp:55-58 */
-        wave_sync();
-        if (cnt == 64) {
-#pragma unroll 8
-            for (int t = 0; t < 64; ++t) g1[(n0 + t) * 64 + lane] = gt_step(s, xs[t], f1, f2, gain);
-        } else {
-            for (int t = 0; t < cnt; ++t) g1[(n0 + t) * 64 + lane] = gt_step(s, xs[t], f1, f2, gain);
+    const long long ntile = (L + kTile - 1) / kTile;
+    if (role == 0) {
+        const int16_t *in = a.in + off;
+        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane], gain = a.tables->gain[lane];
+        GtState s = {0, 0, 0, 0, 0, 0, 0, 0};
+        float xnext = (lane < kTile && lane < L) ? (float)in[lane] : 0.0f; /* extractwav.cpp:55-58 */
+        for (long long j = 0; j <= ntile; ++j) {
+            if (j < ntile) {
+                const long long n0 = j * kTile;
+                if (lane < kTile) xs[lane] = xnext;
+                const long long nn = n0 + kTile + lane;
+                if (lane < kTile) xnext = (nn < L) ? (float)in[nn] : 0.0f;
+                wave_sync();
+                float(*g)[64] = gbuf[j & 1];
+#pragma unroll
+                for (int t = 0; t < kTile; ++t) g[t][lane] = gt_step(s, xs[t], f1, f2, gain);
+                wave_sync();
+            }
+            pair_sync();
+        }
+    } else {
+        float *rin = a.inter + off * 64 + lane;
+        const float ear = a.tables->midEar[lane];
+        for (long long j = 0; j <= ntile; ++j) {
+            if (j >= 1) {
+                const long long n0 = (j - 1) * kTile;
+                const int cnt = (L - n0 < kTile) ? (int)(L - n0) : kTile;
+                const float(*g)[64] = gbuf[(j - 1) & 1];
+#pragma unroll
+                for (int t = 0; t < kTile; ++t)
+                    if (t < cnt) rin[(n0 + t) * 64] = g[t][lane] / ear;
+            }
+            pair_sync();
         }
     }
 }
@@ -88,69 +127,110 @@ __global__ __launch_bounds__(64) void gammatone_kernel(const float *in, float *o
     for (long long n = 0; n < L; ++n) out[n] = gt_step(s, in[n], f1, f2, gain);
 }
 
-__global__ __launch_bounds__(64) void resynth_bwd_kernel(ResynthArgs a)
+/* Synthesis pass.  Workgroup = one utterance = two waves, lane = channel:
+ *   wave A  reads the rows of the intermediate in reverse time order (8 rows in flight per lane) and
+ *           runs the second recurrence (extractwav.cpp:88), 16 steps per tile into LDS
+ *   wave B  takes the previous tile: divides by the middle-ear gain (:89-90), evaluates the
+ *           mask-weighted raised-cosine overlap-add weight of that output sample on the fly (at most
+ *           two overlapping frames per sample, :91-107), multiplies (:108-112), and sums the 64
+ *           channels IN CHANNEL ORDER through a padded LDS transpose (lane = sample), truncates to
+ *           int16 (:120-121) and stores. */
+__global__ __launch_bounds__(128) void resynth_bwd_kernel(ResynthArgs a)
 {
-    __shared__ float tile[64 * kTileStride];
+    __shared__ __attribute__((aligned(16))) float gbuf[2][kTile][64];
+    __shared__ float prod[kTile * kTileStride];
     __shared__ double olaUp[160], olaDown[160];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long off = a.offsets[u], L = a.lengths[u];
-    if (L < 320) return; /* no mask frame fits: the reference would index before the array */
-    const long long F = (L - 320) / 160 + 1;
-    const float *g1 = a.inter + off * 64;
-    const float *mask = a.mask + a.mask_offsets[u] * 64;
-    int16_t *out = a.out + off;
-    const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane], gain = a.tables->gain[lane];
-    const float ear = a.tables->midEar[lane];
-    const bool binary = a.binary != 0;
-    for (int i = lane; i < 160; i += 64) {
+    if (L < 320) return; /* no mask frame fits (wave-uniform exit before any barrier) */
+    const long long ntile = (L + kTile - 1) / kTile;
+    for (int i = threadIdx.x; i < 160; i += 128) {
         olaUp[i] = a.tables->olaUp[i];
         olaDown[i] = a.tables->olaDown[i];
     }
-    wave_sync();
+    pair_sync();
 
-    GtState s = {0, 0, 0, 0, 0, 0, 0, 0};
-    /* mask rows of the hop that contains output sample m (h) and of the next hop (h+1) */
-    long long hop = -1;
-    float mh = 0.0f, mh1 = 0.0f;
-
-    for (long long n0 = 0; n0 < L; n0 += 64) {
-        const int cnt = (L - n0 < 64) ? (int)(L - n0) : 64;
-        for (int t = 0; t < cnt; ++t) {
-            const long long n = n0 + t, m = L - 1 - n;
-            /* reverse[n] = g1[L-1-n] / midEar (extractwav.cpp:86-87), second pass (:88) */
-            const float rin = g1[m * 64 + lane] / ear;
-            const float g2 = gt_step(s, rin, f1, f2, gain);
-            /* reverse[L-1-n] = g2[n] / midEar (:89-90): the value that lands on output sample m */
-            const float v = g2 / ear;
-            /* overlap-add weight of sample m (:91-107): falling half of frame h, then rising half
-             * of frame h+1, each added as float(double(w) + half * mask) */
-            const long long h = m / 160;
-            const int r = (int)(m - h * 160);
-            if (h != hop) {
-                hop = h;
-                mh = (h < F) ? mask[h * 64 + lane] : 0.0f;
-                mh1 = (h + 1 < F) ? mask[(h + 1) * 64 + lane] : 0.0f;
-                if (binary) { /* IBM: > 0.5 becomes 1.0, everything else is skipped */
-                    mh = (mh > 0.5f) ? 1.0f : 0.0f;
-                    mh1 = (mh1 > 0.5f) ? 1.0f : 0.0f;
+    if (role == 0) {
+        const float *rin = a.inter + off * 64 + lane;
+        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane], gain = a.tables->gain[lane];
+        GtState s = {0, 0, 0, 0, 0, 0, 0, 0};
+        constexpr int kAhead = 8;
+        float cur[kAhead], nxt[kAhead];
+#pragma unroll
+        for (int k = 0; k < kAhead; ++k) cur[k] = (k < L) ? rin[(L - 1 - k) * 64] : 0.0f;
+        for (long long j = 0; j <= ntile; ++j) {
+            if (j < ntile) {
+                float(*g)[64] = gbuf[j & 1];
+#pragma unroll
+                for (int t0 = 0; t0 < kTile; t0 += kAhead) {
+#pragma unroll
+                    for (int k = 0; k < kAhead; ++k) { /* time runs backwards: row index decreases */
+                        const long long nn = j * kTile + t0 + kAhead + k;
+                        nxt[k] = (nn < L) ? rin[(L - 1 - nn) * 64] : 0.0f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < kAhead; ++k) g[t0 + k][lane] = gt_step(s, cur[k], f1, f2, gain);
+#pragma unroll
+                    for (int k = 0; k < kAhead; ++k) cur[k] = nxt[k];
                 }
             }
-            float w = 0.0f;
-            if (mh > 0.0f) w = (float)((double)w + olaDown[r] * (double)mh);
-            if (mh1 > 0.0f) w = (float)((double)w + olaUp[r] * (double)mh1);
-            tile[t * kTileStride + lane] = w * v; /* :108-112 term of this channel */
+            pair_sync();
         }
-        wave_sync();
-        /* channel sum in order 0..63 for sample t = lane, then the (short) cast (:120-121) */
-        if (lane < cnt) {
-            float acc = 0.0f;
-            const float *row = tile + lane * kTileStride;
+    } else {
+        const long long F = (L - 320) / 160 + 1;
+        const float *mask = a.mask + a.mask_offsets[u] * 64 + lane;
+        int16_t *out = a.out + off;
+        const float ear = a.tables->midEar[lane];
+        const bool binary = a.binary != 0;
+        /* mask value of row h as the weight code sees it: the IBM variant turns > 0.5 into 1.0 and
+         * skips everything else (resyth_64sub_IBM/cpp/extractwav.cpp:97-99); skipped == 0 here */
+        auto mask_row = [&](long long h) -> float {
+            if (h < 0 || h >= F) return 0.0f;
+            const float v = mask[h * 64];
+            return binary ? ((v > 0.5f) ? 1.0f : 0.0f) : v;
+        };
+        /* output sample m = L-1-n runs backwards through hops of 160: r = m % 160 counts down.
+         * mh / mh1: mask rows of hop h (falling half) and h+1 (rising half); mhPrev: row h-1,
+         * fetched one hop ahead so that its latency is never exposed. */
+        long long h = (L - 1) / 160;
+        int r = (int)((L - 1) - h * 160);
+        float mh = mask_row(h), mh1 = mask_row(h + 1), mhPrev = mask_row(h - 1);
+        for (long long j = 0; j <= ntile; ++j) {
+            if (j >= 1) {
+                const long long n0 = (j - 1) * kTile;
+                const int cnt = (L - n0 < kTile) ? (int)(L - n0) : kTile;
+                const float(*g)[64] = gbuf[(j - 1) & 1];
+#pragma unroll 4
+                for (int t = 0; t < kTile; ++t) {
+                    if (t < cnt) {
+                        const float v = g[t][lane] / ear; /* the value landing on output sample m */
+                        float w = 0.0f; /* falling half of frame h first, then rising half of h+1 */
+                        if (mh > 0.0f) w = (float)((double)w + olaDown[r] * (double)mh);
+                        if (mh1 > 0.0f) w = (float)((double)w + olaUp[r] * (double)mh1);
+                        prod[t * kTileStride + lane] = w * v;
+                        if (--r < 0) { /* step into hop h-1 */
+                            r = 159;
+                            h--;
+                            mh1 = mh;
+                            mh = mhPrev;
+                            mhPrev = mask_row(h - 1);
+                        }
+                    }
+                }
+                wave_sync();
+                if (lane < cnt) { /* channel sum in order 0..63 for sample t = lane */
+                    float acc = 0.0f;
+                    const float *row = prod + lane * kTileStride;
 #pragma unroll 16
-            for (int c = 0; c < 64; ++c) acc += row[c];
-            out[L - 1 - (n0 + lane)] = (int16_t)cast_i16(acc);
+                    for (int c = 0; c < 64; ++c) acc += row[c];
+                    out[L - 1 - (n0 + lane)] = (int16_t)cast_i16(acc);
+                }
+                wave_sync();
+            }
+            pair_sync();
         }
-        wave_sync();
     }
 }
 

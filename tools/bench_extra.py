@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""tools/bench_extra.py -- measurements of the other hot-path kernels (BASELINE configs[2], [3] and
+the CompCeps front-end) on one MI355X.  bench.py stays the headline (NoiseSup, configs[1]); this
+script prints one JSON line per workload with the same roofline convention.
+
+    python tools/bench_extra.py [--utts 1024] [--steps 5] [--what resynth,ibm,ceps,rfft]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (build_shard)
+
+HBM_PEAK_GBPS = 8000.0
+
+
+def timed(fn, steps, warmup=1):
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    return wall, float(np.mean([a.elapsed_time(b) for a, b in ev])) / 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--utts", type=int, default=1024)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--what", default="resynth,ibm,ceps,rfft")
+    args = ap.parse_args()
+    import torch
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    what = set(args.what.split(","))
+    batch = bench.build_shard(args.utts, 0, dev)
+    audio_s = float(np.sum(batch.host_lengths)) / 16000.0
+
+    if what & {"resynth", "ibm"}:
+        masks = sea.MaskBatch.from_arrays([corpus.synth_mask(u, int(L)) for u, L in enumerate(batch.host_lengths)], dev)
+        hops = int(np.sum((np.asarray(batch.host_lengths) - 320) // 160 + 1))
+        scratch = torch.empty(batch.total * 64, dtype=torch.float32, device=dev)
+        out = torch.zeros_like(batch.data)
+        for name, binary in (("resynth", False), ("ibm", True)):
+            if name not in what:
+                continue
+            wall, ker = timed(lambda: sea.resynth_batch(batch, masks, binary=binary, out=out, scratch=scratch), args.steps)
+            alg = hops * 896
+            print(json.dumps({
+                "metric": f"resynth_64sub_{'IBM' if binary else 'ori'} hop-frames/sec (160-sample hop, 64 bands)",
+                "value": hops / wall, "unit": "hop-frames/s", "ms_per_step": wall * 1e3, "rtf": wall / audio_s,
+                "config": {"workload": f"BASELINE configs[{3 if binary else 2}]: {args.utts} utterances, 64-band gammatone "
+                                       f"analysis/synthesis, {'ideal binary' if binary else 'ratio'} mask", "hop_frames": hops},
+                "roofline": {"bound": "hbm", "kernels": "sea::resynth_fwd_kernel + sea::resynth_bwd_kernel",
+                             "achieved": alg / ker / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": alg / ker / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": alg,
+                             "intermediate_bytes_per_step": int(batch.total) * 64 * 4 * 2,
+                             "intermediate_GBps": int(batch.total) * 64 * 4 * 2 / ker / 1e9, "avg_step_ms": ker * 1e3}}),
+                  flush=True)
+
+    if "ceps" in what:
+        out, f32, first = sea.ns_denoise_batch(batch, want_f32=True)
+        torch.cuda.synchronize()
+        res = {}
+
+        def run():
+            res["c"] = sea.compceps_batch(batch, f32, first)
+        wall, ker = timed(run, args.steps)
+        n = int(res["c"][2].sum().item())
+        alg = n * (320 + 56)
+        print(json.dumps({"metric": "CompCeps cepstral frames/sec (from the float NoiseSup stream)", "value": n / wall,
+                          "unit": "frames/s", "ms_per_step": wall * 1e3,
+                          "config": {"workload": f"{args.utts} utterances, {n} cepstral frames of 14 coefficients"},
+                          "roofline": {"bound": "hbm", "kernel": "sea::compceps_kernel", "achieved": alg / ker / 1e9,
+                                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / ker / 1e9 / HBM_PEAK_GBPS,
+                                       "algorithmic_bytes_per_step": alg, "avg_step_ms": ker * 1e3}}), flush=True)
+
+    if "rfft" in what:
+        n = 1 << 18
+        x = torch.randn(n, 256, device=dev)
+        wall, ker = timed(lambda: sea.rfft_batch(x), args.steps)
+        alg = n * 2048
+        print(json.dumps({"metric": "rfft256 frames/sec", "value": n / wall, "unit": "frames/s", "ms_per_step": wall * 1e3,
+                          "config": {"workload": f"{n} frames of 256 floats"},
+                          "roofline": {"bound": "hbm", "kernel": "sea::rfft256_kernel", "achieved": alg / ker / 1e9,
+                                       "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / ker / 1e9 / HBM_PEAK_GBPS,
+                                       "avg_step_ms": ker * 1e3}}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
