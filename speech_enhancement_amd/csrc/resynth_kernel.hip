@@ -202,10 +202,32 @@ __global__ __launch_bounds__(128) void resynth_bwd_kernel(ResynthArgs a)
                 const long long n0 = (j - 1) * kTile;
                 const int cnt = (L - n0 < kTile) ? (int)(L - n0) : kTile;
                 const float(*g)[64] = gbuf[(j - 1) & 1];
-#pragma unroll 4
-                for (int t = 0; t < kTile; ++t) {
-                    if (t < cnt) {
+                if (cnt == kTile && r >= kTile - 1) {
+                    /* whole tile inside one hop (9 tiles out of 10): branch-free, 16 independent
+                     * steps for the scheduler.  float(double(0.0f) + x) == float(x), so the first
+                     * accumulation needs no add. */
+                    const double mhD = (double)mh, mh1D = (double)mh1;
+                    const bool useH = mh > 0.0f, useH1 = mh1 > 0.0f;
+#pragma unroll
+                    for (int t = 0; t < kTile; ++t) {
                         const float v = g[t][lane] / ear; /* the value landing on output sample m */
+                        const float w1 = (float)(olaDown[r - t] * mhD);
+                        float w = useH ? w1 : 0.0f;
+                        const float w2 = (float)((double)w + olaUp[r - t] * mh1D);
+                        w = useH1 ? w2 : w;
+                        prod[t * kTileStride + lane] = w * v;
+                    }
+                    r -= kTile;
+                    if (r < 0) { /* step into hop h-1 */
+                        r += 160;
+                        h--;
+                        mh1 = mh;
+                        mh = mhPrev;
+                        mhPrev = mask_row(h - 1);
+                    }
+                } else {
+                    for (int t = 0; t < cnt; ++t) {
+                        const float v = g[t][lane] / ear;
                         float w = 0.0f; /* falling half of frame h first, then rising half of h+1 */
                         if (mh > 0.0f) w = (float)((double)w + olaDown[r] * (double)mh);
                         if (mh1 > 0.0f) w = (float)((double)w + olaUp[r] * (double)mh1);
