@@ -325,9 +325,9 @@ int sea_resynth64_batch(const short *d_in, short *d_out, const long long *d_offs
     a.tables = c->gt;
     a.n_utt = n_utt;
     a.binary = binary;
-    hipLaunchKernelGGL(sea::resynth_fwd_kernel, dim3(n_utt), dim3(128), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(sea::resynth_fwd_kernel, dim3(n_utt), dim3(192), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(sea::resynth_bwd_kernel, dim3(n_utt), dim3(128), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(sea::resynth_bwd_kernel, dim3(n_utt), dim3(192), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

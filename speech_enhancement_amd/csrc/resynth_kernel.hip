@@ -1,21 +1,29 @@
 /*
  * resynth_kernel.hip -- Hu-Wang 64-channel gammatone analysis/synthesis resynthesis, gfx950.
  *
- * One workgroup (two 64-lane wavefronts) owns one utterance; LANE = CHANNEL (64 channels = one
- * wave), so the 4th-order complex one-pole cascade of every channel advances one sample per step in
- * lock-step.  The serial recurrence has a wave to itself; everything that is per-sample but not
- * recursive (divisions, overlap-add weights, channel sums, stores) runs one 16-step tile behind in a
- * helper wave.
+ * One workgroup (three 64-lane wavefronts) owns one utterance; LANE = CHANNEL (64 channels = one
+ * wave), so the 4th-order complex one-pole cascade of every channel advances one sample per step
+ * in lock-step.  A wave that is alone on its SIMD issues one vector instruction every 4 cycles, so
+ * the ~49 operations of one cascade step bound a one-wave recurrence at ~200 cycles per sample.  The
+ * cascade is therefore cut in two feed-forward halves that run as a software pipeline, 16-sample
+ * tiles through LDS, one s_barrier per tile:
  *
- *   resynth_fwd_kernel : analysis pass.  g1[n][c] written to HBM as rows of 64 floats (256 B per
- *                        step, fully coalesced).  288 GB of HBM is what makes keeping the whole
- *                        [L][64] intermediate of a 1024-utterance batch (~17 GB) resident feasible.
- *   resynth_bwd_kernel : reads the rows in reverse time order, divides by the middle-ear gain,
- *                        re-filters, divides again, evaluates the mask-weighted raised-cosine
- *                        overlap-add weight of that sample on the fly (at most two overlapping
- *                        frames per sample), multiplies, and sums the 64 channels IN CHANNEL ORDER
- *                        through a padded LDS transpose (64 samples at a time, lane = sample), then
- *                        truncates to int16.  No second intermediate is written.
+ *   wave R1  cascade stages 0-1 (state p0,q0,p1,q1)          -> (p1,q1) per sample
+ *   wave R2  cascade stages 2-3 (state p2,q2,p3,q3; it re-derives x1,y1 from the previous
+ *            (p1,q1), which it already holds)                -> filter output per sample
+ *   wave H   everything per-sample but not recursive: divisions by the middle-ear gain, the
+ *            overlap-add weights, channel sums, casts, HBM stores
+ *
+ *   resynth_fwd_kernel : analysis pass; H writes g1[n][c]/midEar[c] to HBM as rows of 64 floats
+ *                        (256 B per step, fully coalesced).  288 GB of HBM is what makes keeping the
+ *                        whole [L][64] intermediate of a 1024-utterance batch (~17 GB) resident
+ *                        feasible.
+ *   resynth_bwd_kernel : R1 reads the rows in reverse time order (8 in flight per lane); H divides
+ *                        again, evaluates the mask-weighted raised-cosine overlap-add weight of
+ *                        that sample on the fly (at most two overlapping frames per sample),
+ *                        multiplies, and sums the 64 channels IN CHANNEL ORDER through a padded LDS
+ *                        transpose (lane = sample), then truncates to int16.  No second
+ *                        intermediate is written.
  *
  * Reference reproduced: resyth_64sub_ori/cpp/extractwav.cpp:55-121 (resynth body; hairCell is dead
  * code there), :167-211 (gammaToneFilter); resyth_64sub_IBM/cpp/extractwav.cpp:97-99
@@ -52,67 +60,117 @@ __device__ __forceinline__ float gt_step(GtState &s, float in, float f1, float f
     return out;
 }
 
-constexpr int kTile = 16;        /* time steps handed from the recurrence wave to the helper wave at once */
+/* The same step cut in two.  Stages 0-1: consumes the input sample, returns the NEW (p1,q1). */
+struct GtLo {
+    float p0, q0, p1, q1;
+};
+__device__ __forceinline__ float2 gt_step_lo(GtLo &s, float in, float f1, float f2)
+{
+    const float x0 = f1 * s.p0 - f2 * s.q0, y0 = f2 * s.p0 + f1 * s.q0;
+    const float x1 = f1 * s.p1 - f2 * s.q1, y1 = f2 * s.p1 + f1 * s.q1;
+    s.p0 = in * f1 + x0;
+    s.q0 = in * f2 + y0;
+    s.p1 = s.p0 + x1;
+    s.q1 = s.q0 + y1;
+    return make_float2(s.p1, s.q1);
+}
+/* Stages 2-3: needs the new (p1,q1) and x1,y1 -- the rotation of the OLD (p1,q1), which this wave
+ * kept from the previous sample, so the same two products and one add/sub reproduce them exactly. */
+struct GtHi {
+    float p1old, q1old, p2, q2, p3, q3;
+};
+__device__ __forceinline__ float gt_step_hi(GtHi &s, float2 pq1, float f1, float f2, float gain)
+{
+    const float out = s.p3 * gain;
+    const float x1 = f1 * s.p1old - f2 * s.q1old, y1 = f2 * s.p1old + f1 * s.q1old;
+    const float x2 = f1 * s.p2 - f2 * s.q2, y2 = f2 * s.p2 + f1 * s.q2;
+    const float x3 = f1 * s.p3 - f2 * s.q3, y3 = f2 * s.p3 + f1 * s.q3;
+    s.p2 = pq1.x + x1 + x2;
+    s.q2 = pq1.y + y1 + y2;
+    s.p3 = s.p2 + x1 + 2 * x2 + x3;
+    s.q3 = s.q2 + y1 + 2 * y2 + y3;
+    s.p1old = pq1.x;
+    s.q1old = pq1.y;
+    return out;
+}
+
+constexpr int kTile = 16;        /* time steps per hand-over between the pipelined waves */
 constexpr int kTileStride = 65;  /* 64 channels + 1 pad: conflict-free row reads by lane = sample */
 
-/* workgroup barrier for the two role-specialised waves (same count, different program counters);
+/* workgroup barrier for the role-specialised waves (same count, different program counters);
  * LDS-only fences: HBM loads and stores stay in flight across it */
-__device__ __forceinline__ void pair_sync()
+__device__ __forceinline__ void tile_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+struct __attribute__((aligned(16))) RsLds {
+    float2 pq[2][kTile][64]; /* R1 -> R2 */
+    float g[2][kTile][64];   /* R2 -> H  */
+};
+
 } // namespace
 
-/* Analysis pass.  Workgroup = one utterance = two waves, lane = channel in both:
- *   wave A  the serial 4-stage recurrence (extractwav.cpp:188-210), 16 steps per tile into LDS
- *   wave B  takes the previous tile, divides by the middle-ear gain (the "reverse[...] = gOut/midEar"
- *           of extractwav.cpp:86-87 -- a per-sample operation that does not belong on the
- *           recurrence's critical chain) and streams rows of 64 floats to HBM (256 B per step).
- * The intermediate therefore holds g1[n][c] / midEar[c] in natural time order. */
-__global__ __launch_bounds__(128) void resynth_fwd_kernel(ResynthArgs a)
+__global__ __launch_bounds__(192) void resynth_fwd_kernel(ResynthArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float gbuf[2][kTile][64];
+    __shared__ RsLds S;
     __shared__ __attribute__((aligned(16))) float xs[kTile];
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long off = a.offsets[u], L = a.lengths[u];
-    const long long ntile = (L + kTile - 1) / kTile;
+    const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 2;
     if (role == 0) {
         const int16_t *in = a.in + off;
-        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane], gain = a.tables->gain[lane];
-        GtState s = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane];
+        GtLo s = {0, 0, 0, 0};
         float xnext = (lane < kTile && lane < L) ? (float)in[lane] : 0.0f; /* extractwav.cpp:55-58 */
-        for (long long j = 0; j <= ntile; ++j) {
+        for (long long j = 0; j < niter; ++j) {
             if (j < ntile) {
-                const long long n0 = j * kTile;
                 if (lane < kTile) xs[lane] = xnext;
-                const long long nn = n0 + kTile + lane;
+                const long long nn = (j + 1) * kTile + lane;
                 if (lane < kTile) xnext = (nn < L) ? (float)in[nn] : 0.0f;
                 wave_sync();
-                float(*g)[64] = gbuf[j & 1];
+                float2(*o)[64] = S.pq[j & 1];
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) g[t][lane] = gt_step(s, xs[t], f1, f2, gain);
+                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_lo(s, xs[t], f1, f2);
                 wave_sync();
             }
-            pair_sync();
+            tile_sync();
+        }
+    } else if (role == 1) {
+        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane], gain = a.tables->gain[lane];
+        GtHi s = {0, 0, 0, 0, 0, 0};
+        for (long long j = 0; j < niter; ++j) {
+            const long long jt = j - 1;
+            if (jt >= 0 && jt < ntile) {
+                const float2(*i)[64] = S.pq[jt & 1];
+                float(*o)[64] = S.g[jt & 1];
+#pragma unroll
+                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_hi(s, i[t][lane], f1, f2, gain);
+            }
+            tile_sync();
         }
     } else {
+        /* reverse[...] = gOut / midEar (extractwav.cpp:86-87), streamed to HBM in natural time order */
         float *rin = a.inter + off * 64 + lane;
         const float ear = a.tables->midEar[lane];
-        for (long long j = 0; j <= ntile; ++j) {
-            if (j >= 1) {
-                const long long n0 = (j - 1) * kTile;
+        for (long long j = 0; j < niter; ++j) {
+            const long long jt = j - 2;
+            if (jt >= 0 && jt < ntile) {
+                const long long n0 = jt * kTile;
                 const int cnt = (L - n0 < kTile) ? (int)(L - n0) : kTile;
-                const float(*g)[64] = gbuf[(j - 1) & 1];
+                const float(*g)[64] = S.g[jt & 1];
+                if (cnt == kTile) {
 #pragma unroll
-                for (int t = 0; t < kTile; ++t)
-                    if (t < cnt) rin[(n0 + t) * 64] = g[t][lane] / ear;
+                    for (int t = 0; t < kTile; ++t) rin[(n0 + t) * 64] = g[t][lane] / ear;
+                } else {
+                    for (int t = 0; t < cnt; ++t) rin[(n0 + t) * 64] = g[t][lane] / ear;
+                }
             }
-            pair_sync();
+            tile_sync();
         }
     }
 }
@@ -127,17 +185,9 @@ __global__ __launch_bounds__(64) void gammatone_kernel(const float *in, float *o
     for (long long n = 0; n < L; ++n) out[n] = gt_step(s, in[n], f1, f2, gain);
 }
 
-/* Synthesis pass.  Workgroup = one utterance = two waves, lane = channel:
- *   wave A  reads the rows of the intermediate in reverse time order (8 rows in flight per lane) and
- *           runs the second recurrence (extractwav.cpp:88), 16 steps per tile into LDS
- *   wave B  takes the previous tile: divides by the middle-ear gain (:89-90), evaluates the
- *           mask-weighted raised-cosine overlap-add weight of that output sample on the fly (at most
- *           two overlapping frames per sample, :91-107), multiplies (:108-112), and sums the 64
- *           channels IN CHANNEL ORDER through a padded LDS transpose (lane = sample), truncates to
- *           int16 (:120-121) and stores. */
-__global__ __launch_bounds__(128) void resynth_bwd_kernel(ResynthArgs a)
+__global__ __launch_bounds__(192) void resynth_bwd_kernel(ResynthArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float gbuf[2][kTile][64];
+    __shared__ RsLds S;
     __shared__ float prod[kTile * kTileStride];
     __shared__ double olaUp[160], olaDown[160];
     const int lane = threadIdx.x & 63;
@@ -145,24 +195,25 @@ __global__ __launch_bounds__(128) void resynth_bwd_kernel(ResynthArgs a)
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long off = a.offsets[u], L = a.lengths[u];
     if (L < 320) return; /* no mask frame fits (wave-uniform exit before any barrier) */
-    const long long ntile = (L + kTile - 1) / kTile;
-    for (int i = threadIdx.x; i < 160; i += 128) {
+    const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 2;
+    for (int i = threadIdx.x; i < 160; i += 192) {
         olaUp[i] = a.tables->olaUp[i];
         olaDown[i] = a.tables->olaDown[i];
     }
-    pair_sync();
+    tile_sync();
 
     if (role == 0) {
+        /* second pass over the time-reversed signal (extractwav.cpp:88), stages 0-1 */
         const float *rin = a.inter + off * 64 + lane;
-        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane], gain = a.tables->gain[lane];
-        GtState s = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane];
+        GtLo s = {0, 0, 0, 0};
         constexpr int kAhead = 8;
         float cur[kAhead], nxt[kAhead];
 #pragma unroll
         for (int k = 0; k < kAhead; ++k) cur[k] = (k < L) ? rin[(L - 1 - k) * 64] : 0.0f;
-        for (long long j = 0; j <= ntile; ++j) {
+        for (long long j = 0; j < niter; ++j) {
             if (j < ntile) {
-                float(*g)[64] = gbuf[j & 1];
+                float2(*o)[64] = S.pq[j & 1];
 #pragma unroll
                 for (int t0 = 0; t0 < kTile; t0 += kAhead) {
 #pragma unroll
@@ -171,12 +222,25 @@ __global__ __launch_bounds__(128) void resynth_bwd_kernel(ResynthArgs a)
                         nxt[k] = (nn < L) ? rin[(L - 1 - nn) * 64] : 0.0f;
                     }
 #pragma unroll
-                    for (int k = 0; k < kAhead; ++k) g[t0 + k][lane] = gt_step(s, cur[k], f1, f2, gain);
+                    for (int k = 0; k < kAhead; ++k) o[t0 + k][lane] = gt_step_lo(s, cur[k], f1, f2);
 #pragma unroll
                     for (int k = 0; k < kAhead; ++k) cur[k] = nxt[k];
                 }
             }
-            pair_sync();
+            tile_sync();
+        }
+    } else if (role == 1) {
+        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane], gain = a.tables->gain[lane];
+        GtHi s = {0, 0, 0, 0, 0, 0};
+        for (long long j = 0; j < niter; ++j) {
+            const long long jt = j - 1;
+            if (jt >= 0 && jt < ntile) {
+                const float2(*i)[64] = S.pq[jt & 1];
+                float(*o)[64] = S.g[jt & 1];
+#pragma unroll
+                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_hi(s, i[t][lane], f1, f2, gain);
+            }
+            tile_sync();
         }
     } else {
         const long long F = (L - 320) / 160 + 1;
@@ -197,11 +261,12 @@ __global__ __launch_bounds__(128) void resynth_bwd_kernel(ResynthArgs a)
         long long h = (L - 1) / 160;
         int r = (int)((L - 1) - h * 160);
         float mh = mask_row(h), mh1 = mask_row(h + 1), mhPrev = mask_row(h - 1);
-        for (long long j = 0; j <= ntile; ++j) {
-            if (j >= 1) {
-                const long long n0 = (j - 1) * kTile;
+        for (long long j = 0; j < niter; ++j) {
+            const long long jt = j - 2;
+            if (jt >= 0 && jt < ntile) {
+                const long long n0 = jt * kTile;
                 const int cnt = (L - n0 < kTile) ? (int)(L - n0) : kTile;
-                const float(*g)[64] = gbuf[(j - 1) & 1];
+                const float(*g)[64] = S.g[jt & 1];
                 if (cnt == kTile && r >= kTile - 1) {
                     /* whole tile inside one hop (9 tiles out of 10): branch-free, 16 independent
                      * steps for the scheduler.  float(double(0.0f) + x) == float(x), so the first
@@ -210,12 +275,12 @@ __global__ __launch_bounds__(128) void resynth_bwd_kernel(ResynthArgs a)
                     const bool useH = mh > 0.0f, useH1 = mh1 > 0.0f;
 #pragma unroll
                     for (int t = 0; t < kTile; ++t) {
-                        const float v = g[t][lane] / ear; /* the value landing on output sample m */
+                        const float v = g[t][lane] / ear; /* :89-90, the value landing on sample m */
                         const float w1 = (float)(olaDown[r - t] * mhD);
                         float w = useH ? w1 : 0.0f;
                         const float w2 = (float)((double)w + olaUp[r - t] * mh1D);
                         w = useH1 ? w2 : w;
-                        prod[t * kTileStride + lane] = w * v;
+                        prod[t * kTileStride + lane] = w * v; /* :108-112 term of this channel */
                     }
                     r -= kTile;
                     if (r < 0) { /* step into hop h-1 */
@@ -228,7 +293,7 @@ __global__ __launch_bounds__(128) void resynth_bwd_kernel(ResynthArgs a)
                 } else {
                     for (int t = 0; t < cnt; ++t) {
                         const float v = g[t][lane] / ear;
-                        float w = 0.0f; /* falling half of frame h first, then rising half of h+1 */
+                        float w = 0.0f; /* :91-107: falling half of frame h, then rising half of h+1 */
                         if (mh > 0.0f) w = (float)((double)w + olaDown[r] * (double)mh);
                         if (mh1 > 0.0f) w = (float)((double)w + olaUp[r] * (double)mh1);
                         prod[t * kTileStride + lane] = w * v;
@@ -242,7 +307,7 @@ __global__ __launch_bounds__(128) void resynth_bwd_kernel(ResynthArgs a)
                     }
                 }
                 wave_sync();
-                if (lane < cnt) { /* channel sum in order 0..63 for sample t = lane */
+                if (lane < cnt) { /* channel sum in order 0..63 for sample t = lane, (short) cast :120-121 */
                     float acc = 0.0f;
                     const float *row = prod + lane * kTileStride;
 #pragma unroll 16
@@ -251,7 +316,7 @@ __global__ __launch_bounds__(128) void resynth_bwd_kernel(ResynthArgs a)
                 }
                 wave_sync();
             }
-            pair_sync();
+            tile_sync();
         }
     }
 }
