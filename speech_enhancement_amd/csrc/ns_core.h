@@ -135,25 +135,47 @@ __device__ __forceinline__ double ns_ln(double x)
     return __fma_rn(de, ln2_hi, __fma_rn(de, ln2_lo, lnm));
 }
 
-/* One PSD bin of FilterCalc (NoiseSup.c:449-563).  P = 2-frame mean PSD, nSig = this frame's PSD.
- * nb is the frame counter narrowed to int16 as the reference does. */
+/* FilterCalc (NoiseSup.c:449-563) for one PSD bin, in two pieces so that the pipelined kernel can
+ * run them in different waves.  nb is the frame counter narrowed to int16 as the reference does
+ * (SURVEY F9).
+ *
+ * Second-stage noise tracking in the energy domain (:486-517): P = 2-frame mean PSD. */
+__device__ __forceinline__ void noise_track1(float P, float &noise, int nb, float eps)
+{
+    float n2 = noise * noise;
+    if (nb < 11) {
+        const float lambda = 1 - 1 / (float)nb;
+        n2 = lambda * n2 + (1 - lambda) * P;
+    } else {
+        const float r1 = P / (P + n2), r2 = P / n2;
+        const float upd = (float)(0.9 + 0.1 * (double)r1 * (1.0 + 1.0 / (1.0 + 0.1 * (double)r2)));
+        n2 *= upd;
+    }
+    n2 = sqrtf(n2);
+    noise = (n2 < eps) ? eps : n2;
+}
+
+/* Wiener gain of one bin given the (already updated) noise magnitude (:522-526, :551-560).
+ * Psqrt = sqrt of the mean PSD, nSigSqrt = sqrt of this frame's PSD. */
+__device__ __forceinline__ float gain_bin(float Psqrt, float nSigSqrt, float noise, float &den)
+{
+    const float beta = (float)0.98, rsbMin = (float)0.079432823;
+    const float post = (Psqrt / noise) - 1;
+    float prio = beta * (den / noise) + (1 - beta) * ((0 > post) ? 0 : post);
+    float W = prio / (1 + prio);
+    prio = W * Psqrt / noise;
+    prio = (prio > rsbMin) ? prio : rsbMin;
+    W = prio / (1 + prio);
+    den = W * nSigSqrt;
+    return W;
+}
+
+/* the whole bin: P = 2-frame mean PSD, nSig = this frame's PSD */
 template <int ST>
 __device__ __forceinline__ float filter_bin(float P, float nSig, float &noise, float &den, int nb,
                                             int flagVAD, float eps)
 {
-    if (ST == 1) { /* non-VAD noise tracking in the energy domain, :486-517 */
-        float n2 = noise * noise;
-        if (nb < 11) {
-            const float lambda = 1 - 1 / (float)nb;
-            n2 = lambda * n2 + (1 - lambda) * P;
-        } else {
-            const float r1 = P / (P + n2), r2 = P / n2;
-            const float upd = (float)(0.9 + 0.1 * (double)r1 * (1.0 + 1.0 / (1.0 + 0.1 * (double)r2)));
-            n2 *= upd;
-        }
-        n2 = sqrtf(n2);
-        noise = (n2 < eps) ? eps : n2;
-    }
+    if (ST == 1) noise_track1(P, noise, nb, eps);
     nSig = sqrtf(nSig); /* :522-526, (float)sqrt((double)x) == correctly rounded sqrtf */
     P = sqrtf(P);
     if (ST == 0) { /* VAD-gated noise tracking in magnitude, :531-546 */
@@ -163,16 +185,7 @@ __device__ __forceinline__ float filter_bin(float P, float nSig, float &noise, f
             noise = (n < eps) ? eps : n;
         }
     }
-    /* :551-560 */
-    const float beta = (float)0.98, rsbMin = (float)0.079432823;
-    const float post = (P / noise) - 1;
-    float prio = beta * (den / noise) + (1 - beta) * ((0 > post) ? 0 : post);
-    float W = prio / (1 + prio);
-    prio = W * P / noise;
-    prio = (prio > rsbMin) ? prio : rsbMin;
-    W = prio / (1 + prio);
-    den = W * nSig;
-    return W;
+    return gain_bin(P, nSig, noise, den);
 }
 
 /* VAD frame log-energy (NoiseSup.c:386-391) from 64 + sum of the 80 squared samples: depends on
@@ -328,6 +341,80 @@ __device__ __forceinline__ void ns_front_dual(const float *bufA, bool actA, floa
     wave_sync();
 }
 
+/* DoMelFB (MelProc.c:82-104): 25 bands over the Wiener gains in B.wbuf, taps in order; lane = band */
+__device__ __forceinline__ float ns_mel_fb(const BackLds &B, const NsConst &C, int lane)
+{
+    float melOut = 0.0f;
+    if (lane < SEA_NMEL) {
+#pragma unroll
+        for (int i = 0; i < SEA_MEL_TAPS; ++i) {
+            const int idx = C.melStart + i;
+            const float t = melOut + B.wbuf[idx < 65 ? idx : 64] * C.melW[i];
+            melOut = (i < C.melLen) ? t : melOut;
+        }
+    }
+    return melOut;
+}
+
+/* DoMelIDCT rows 0..8 (MelProc.c:357-378), mirror + Hanning(17) (NoiseSup.c:660-669), then ApplyWF:
+ * the 17-tap FIR over buf[80..159] with 8 samples of context either side (NoiseSup.c:324-340);
+ * lanes 0..39 produce two outputs each into dst.  Ends with wave_sync().
+ * LDSBASIS: the 9x25 basis sits in LDS ([f][16], lane = row) instead of 25 VGPRs per lane. */
+template <bool LDSBASIS>
+__device__ __forceinline__ void ns_idct_fir(float melOut, BackLds &B, const NsConst &C, const float *buf,
+                                            float *dst, int lane, const float *idctLds)
+{
+    if (lane < SEA_NMEL) B.mel[lane] = melOut;
+    wave_sync();
+    if (lane <= 8) {
+        float h = 0.0f;
+#pragma unroll
+        for (int f4 = 0; f4 < 24; f4 += 4) {
+            const float4 m = *reinterpret_cast<const float4 *>(&B.mel[f4]);
+            h += m.x * (LDSBASIS ? idctLds[(f4 + 0) * 16 + lane] : C.idct[f4]);
+            h += m.y * (LDSBASIS ? idctLds[(f4 + 1) * 16 + lane] : C.idct[f4 + 1]);
+            h += m.z * (LDSBASIS ? idctLds[(f4 + 2) * 16 + lane] : C.idct[f4 + 2]);
+            h += m.w * (LDSBASIS ? idctLds[(f4 + 3) * 16 + lane] : C.idct[f4 + 3]);
+        }
+        h += B.mel[24] * (LDSBASIS ? idctLds[24 * 16 + lane] : C.idct[24]);
+        const float tap = h * C.irWin;
+        B.fir[8 + lane] = tap;
+        B.fir[8 - lane] = tap;
+    }
+    wave_sync();
+    {
+        float c[SEA_NTAP]; /* the taps are wave-uniform: broadcast LDS reads */
+#pragma unroll
+        for (int k4 = 0; k4 < 16; k4 += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(&B.fir[k4]);
+            c[k4] = v.x;
+            c[k4 + 1] = v.y;
+            c[k4 + 2] = v.z;
+            c[k4 + 3] = v.w;
+        }
+        c[16] = B.fir[16];
+        if (lane < 40) {
+            float x[18];
+            const float *src = buf + 72 + 2 * lane; /* x[m] = buf[72 + 2l + m] */
+#pragma unroll
+            for (int m = 0; m < 18; m += 2) {
+                const float2 v = *reinterpret_cast<const float2 *>(src + m);
+                x[m] = v.x;
+                x[m + 1] = v.y;
+            }
+            float y0 = 0.0f, y1 = 0.0f;
+            /* out[i] = sum_{j=-8..8} fir[j+8] * buf[80+i-j]; i = 2l -> buf index 72+2l+(8-j) */
+#pragma unroll
+            for (int k = 0; k < SEA_NTAP; ++k) {
+                y0 += c[k] * x[16 - k];
+                y1 += c[k] * x[17 - k];
+            }
+            *reinterpret_cast<float2 *>(dst + 2 * lane) = make_float2(y0, y1);
+        }
+    }
+    wave_sync();
+}
+
 /* BACK half of a stage (ST = 0 first, 1 second): everything recursive.  Consumes psd[0..64] and
  * the stage buffer (raw frame buf[80..159] for the VAD, buf[72..167] for the FIR), updates the
  * per-utterance state and deposits the 80 filtered samples in dst.  Ends with wave_sync().
@@ -379,16 +466,7 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     }
     wave_sync();
 
-    /* --- DoMelFB: 25 bands, taps in order (MelProc.c:82-104) --- */
-    float melOut = 0.0f;
-    if (lane < SEA_NMEL) {
-#pragma unroll
-        for (int i = 0; i < SEA_MEL_TAPS; ++i) {
-            const int idx = C.melStart + i;
-            const float t = melOut + B.wbuf[idx < 65 ? idx : 64] * C.melW[i];
-            melOut = (i < C.melLen) ? t : melOut;
-        }
-    }
+    float melOut = ns_mel_fb(B, C, lane);
 
     /* --- DoGainFact (NoiseSup.c:581-642) --- */
     if (!(PIPE && ST == 0)) {
@@ -406,63 +484,60 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
             melOut = (float)((double)(s.alfaGF * melOut) + (1.0 - (double)s.alfaGF) * 1.0);
         }
     }
-    if (lane < SEA_NMEL) B.mel[lane] = melOut;
-    if (lane >= SEA_NMEL && lane < 28) B.mel[lane] = 0.0f; /* padding read by the float4 loads below */
-    wave_sync();
+    ns_idct_fir<PIPE>(melOut, B, C, buf, dst, lane, idctLds);
+}
 
-    /* --- DoMelIDCT rows 0..8 (MelProc.c:357-378), mirror + Hanning(17) (NoiseSup.c:660-669) --- */
-    if (lane <= 8) {
-        float h = 0.0f;
-#pragma unroll
-        /* PIPE: the 9x25 basis sits in LDS ([f][16], lane = row) instead of 25 VGPRs per lane */
-        for (int f4 = 0; f4 < 24; f4 += 4) {
-            const float4 m = *reinterpret_cast<const float4 *>(&B.mel[f4]);
-            h += m.x * (PIPE ? idctLds[(f4 + 0) * 16 + lane] : C.idct[f4]);
-            h += m.y * (PIPE ? idctLds[(f4 + 1) * 16 + lane] : C.idct[f4 + 1]);
-            h += m.z * (PIPE ? idctLds[(f4 + 2) * 16 + lane] : C.idct[f4 + 2]);
-            h += m.w * (PIPE ? idctLds[(f4 + 3) * 16 + lane] : C.idct[f4 + 3]);
-        }
-        h += B.mel[24] * (PIPE ? idctLds[24 * 16 + lane] : C.idct[24]);
-        const float tap = h * C.irWin;
-        B.fir[8 + lane] = tap;
-        B.fir[8 - lane] = tap;
-    }
-    wave_sync();
-
-    /* --- ApplyWF: 17-tap FIR over buf[80..159] with 8 samples context either side
-     *     (NoiseSup.c:324-340); lanes 0..39 produce two outputs each.  The taps are wave-uniform:
-     *     they are moved to scalar registers --- */
+/* ---- the second-stage BACK half cut in two for the pipelined kernel --------------------------------
+ * ns_noise1 (wave N1): PSDMean, the non-VAD noise tracking of all 65 bins, the in-order sum of the
+ *   noise spectrum and the gain-factor scalars (NoiseSup.c:289-303, :486-517, :600-637).  None of it
+ *   depends on the Wiener gains, so it runs one frame ahead of ns_gain1.  Writes P[0..64] (mean PSD),
+ *   noise[0..64] and returns alfaGF; the caller has loaded s.denEn0..2.
+ * ns_gain1 (wave B1): the gains of all bins from (P, PSD, noise), mel filter bank, gain
+ *   factorisation of the 25 mel gains, IDCT, FIR (:522-560, MelProc.c, :639-640, :324-340). */
+__device__ __forceinline__ float ns_noise1(const float *psd, float *Pout, float *noiseOut, NsRegs &s, float eps,
+                                           int lane)
+{
+    const float nSigLo = psd[lane], nSigHi = psd[64];
+    const float PLo = (s.prevLo[1] + nSigLo) * 0.5f;
+    const float PHi = (s.prevHi[1] + nSigHi) * 0.5f;
+    s.prevLo[1] = nSigLo;
+    s.prevHi[1] = nSigHi;
     {
-        float c[SEA_NTAP];
-#pragma unroll
-        for (int k4 = 0; k4 < 16; k4 += 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(&B.fir[k4]);
-            c[k4] = uniform_f(v.x);
-            c[k4 + 1] = uniform_f(v.y);
-            c[k4 + 2] = uniform_f(v.z);
-            c[k4 + 3] = uniform_f(v.w);
-        }
-        c[16] = uniform_f(B.fir[16]);
-        if (lane < 40) {
-            float x[18];
-            const float *src = buf + 72 + 2 * lane; /* x[m] = buf[72 + 2l + m] */
-#pragma unroll
-            for (int m = 0; m < 18; m += 2) {
-                const float2 v = *reinterpret_cast<const float2 *>(src + m);
-                x[m] = v.x;
-                x[m + 1] = v.y;
-            }
-            float y0 = 0.0f, y1 = 0.0f;
-            /* out[i] = sum_{j=-8..8} fir[j+8] * buf[80+i-j]; i = 2l -> buf index 72+2l+(8-j) */
-#pragma unroll
-            for (int k = 0; k < SEA_NTAP; ++k) {
-                y0 += c[k] * x[16 - k];
-                y1 += c[k] * x[17 - k];
-            }
-            *reinterpret_cast<float2 *>(dst + 2 * lane) = make_float2(y0, y1);
-        }
+        int nb = s.nbFrame[1];
+        if (nb < 2147483647) nb++;
+        s.nbFrame[1] = nb;
+    }
+    const int nb16 = (int)(short)s.nbFrame[1];
+    noise_track1(PLo, s.noiseLo[1], nb16, eps);
+    noise_track1(PHi, s.noiseHi[1], nb16, eps);
+    Pout[lane] = PLo;
+    noiseOut[lane] = s.noiseLo[1];
+    if (lane == 0) {
+        Pout[64] = PHi;
+        noiseOut[64] = s.noiseHi[1];
     }
     wave_sync();
+#ifdef SEA_ABLATE_GSUM
+    const float total = noiseOut[0] + noiseOut[64];
+#else
+    const float total = serial_sum<65>(noiseOut, 0.0f);
+#endif
+    gain_fact_update(s, total);
+    return s.alfaGF;
+}
+
+__device__ __forceinline__ void ns_gain1(const float *psd, const float *P, const float *noise, float alfaGF,
+                                         const float *buf, BackLds &B, NsRegs &s, const NsConst &C, float *dst,
+                                         int lane, const float *idctLds)
+{
+    const float WLo = gain_bin(sqrtf(P[lane]), sqrtf(psd[lane]), noise[lane], s.denLo[1]);
+    const float WHi = gain_bin(sqrtf(P[64]), sqrtf(psd[64]), noise[64], s.denHi[1]);
+    B.wbuf[lane] = WLo;
+    if (lane == 0) B.wbuf[64] = WHi;
+    wave_sync();
+    float melOut = ns_mel_fb(B, C, lane);
+    melOut = (float)((double)(alfaGF * melOut) + (1.0 - (double)alfaGF) * 1.0);
+    ns_idct_fir<true>(melOut, B, C, buf, dst, lane, idctLds);
 }
 
 /* One whole stage on the single-wave form: stage 0 deposits its 80 output samples in

@@ -265,9 +265,12 @@ __device__ __forceinline__ void rfft256_head(float e0, float e1, float e2, float
     *reinterpret_cast<float4 *>(work + 4 * r) = make_float4(g0, g1, g2, g3);
 }
 
-/* two transforms at once: eA / eB hold the lane's four (windowed) elements of frame A / B */
-__device__ __forceinline__ void rfft256_dual(const float (&eA)[4], const float (&eB)[4], float *work,
-                                             const Fft2Regs &R, unsigned flags, int lane)
+/* two transforms at once: eA / eB hold the lane's four (windowed) elements of frame A / B.
+ * The transform is offered in two halves so that a pipelined kernel can run them in different
+ * waves (one frame apart): _lo = register-resident start + levels n2 = 8, 16, 32; _hi = levels
+ * n2 = 64, 128, 256.  Both end with wave_sync(). */
+__device__ __forceinline__ void rfft256_dual_lo(const float (&eA)[4], const float (&eB)[4], float *work,
+                                                const Fft2Regs &R, unsigned flags, int lane)
 {
     rfft256_head(eA[0], eA[1], eA[2], eA[3], work, flags, lane);
     rfft256_head(eB[0], eB[1], eB[2], eB[3], work + 256, flags, lane);
@@ -278,12 +281,23 @@ __device__ __forceinline__ void rfft256_dual(const float (&eA)[4], const float (
     wave_sync();
     fft2_level<2>(work, R);
     wave_sync();
+}
+
+__device__ __forceinline__ void rfft256_dual_hi(float *work, const Fft2Regs &R)
+{
     fft2_level<3>(work, R);
     wave_sync();
     fft2_level<4>(work, R);
     wave_sync();
     fft2_level<5>(work, R);
     wave_sync();
+}
+
+__device__ __forceinline__ void rfft256_dual(const float (&eA)[4], const float (&eB)[4], float *work,
+                                             const Fft2Regs &R, unsigned flags, int lane)
+{
+    rfft256_dual_lo(eA, eB, work, R, flags, lane);
+    rfft256_dual_hi(work, R);
 }
 
 /* float -> int16 exactly as the reference's (short) cast behaves on x86-64: truncate toward zero
