@@ -109,6 +109,14 @@ int sea_resynth64(const short *in, long L, const float *mask, int F, int binary,
 /* many utterances at once from host memory (masks[u] is [F_u][64]); one pair of launches */
 int sea_resynth_utterances(const short *const *in, const long *lengths, const float *const *masks, int binary,
                            short *const *out, int n_utt);
+/* subbband() (enhancement_extract_test/cpp/extractwav.cpp:40-101): gammatone + Meddis hair cell
+ * (resyth_64sub_ori/cpp/extractwav.cpp:212-257) + (short) cast -> 64 int16 streams.
+ * Host form: out is [64][L].  Batch form (device pointers): utterance u's streams form a [64][pitch]
+ * block at d_out + d_offsets[u]*64 with pitch = lengths[u] rounded up to 8; d_out holds 64x the
+ * packed input size. */
+int sea_subband64(const short *in, long L, short *out);
+int sea_subband64_batch(const short *d_in, short *d_out, const long long *d_offsets, const long long *d_lengths,
+                        const int *d_order, int n_utt, void *stream);
 /* gammaToneFilter(input, output, fChan, sigLength) for channel `chan` of the 64-band bank */
 int sea_gammatone_filter(const float *input, float *output, int chan, long sigLength);
 

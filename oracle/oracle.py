@@ -123,6 +123,20 @@ class Oracle(_Lib):
                                ctypes.c_float(mid_ear), ctypes.c_long(x.size))
         return y
 
+    def haircell(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.zeros_like(x)
+        self.lib.ora_haircell(_ptr(x), _ptr(y), ctypes.c_long(x.size))
+        return y
+
+    def subband64(self, x):
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        out = np.zeros((64, x.size), np.int16)
+        rc = self.lib.ora_subband64(_ptr(x), ctypes.c_long(x.size), _ptr(out))
+        if rc:
+            raise ValueError("ora_subband64: bad L")
+        return out
+
     def resynth_channels(self):
         cf, bw, me = (np.zeros(64, np.float32) for _ in range(3))
         self.lib.ora_resynth_channels(_ptr(cf), _ptr(bw), _ptr(me))

@@ -156,3 +156,67 @@ int ora_resynth64(const short *in, long L, const float *mask, int F, int binary,
     free(acc);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * the analysis half on its own -- subbband(): gammatone + Meddis hair cell ->
+ * 64 int16 streams (enhancement_extract_test/cpp/extractwav.cpp:40-101; hairCell
+ * resyth_64sub_ori/cpp/extractwav.cpp:212-257; constants HuWang.h:36-44).
+ * PARITY UNPINNED: the reference cannot be built here (asdk Wave.h) and no reference output of
+ * this function was recorded; the restatement follows the C++ promotions literally (MED_* are
+ * double literals, dt is float).
+ * ---------------------------------------------------------------------------------------- */
+void ora_haircell(const float *input, float *output, long L)
+{
+    const double Y = 5.05, G = 2000.0, Lc = 2500.0, R = 6580.0, X = 66.31, A = 3.0, B = 300.0, H = 48000.0, M = 1.0;
+    const float dt = 1 / (float)FS;
+    const float ymdt = (float)(Y * M * dt), xdt = (float)(X * dt), ydt = (float)(Y * dt);
+    const float lplusrdt = (float)((Lc + R) * dt), rdt = (float)(R * dt), gdt = (float)(G * dt), hdt = (float)H;
+    float kt = (float)(G * A / (A + B));
+    float c = (float)(M * Y * kt / (Lc * kt + Y * (Lc + R)));
+    float q = (float)(c * (Lc + R) / kt);
+    float w = (float)(c * R / X);
+    long n;
+    for (n = 0; n < L; n++) {
+        float replenish, eject, reuptakeandloss, reuptake, reprocess;
+        kt = ((input[n] + A) > 0.0) ? (float)(gdt * (input[n] + A) / (input[n] + A + B)) : (float)0;
+        replenish = (q < M) ? (ymdt - ydt * q) : 0;
+        eject = kt * q;
+        reuptakeandloss = lplusrdt * c;
+        reuptake = rdt * c;
+        reprocess = xdt * w;
+        q = q + replenish - eject + reprocess;
+        if (q < 0.0) q = 0.0;
+        c = c + eject - reuptakeandloss;
+        if (c < 0.0) c = 0.0;
+        w = w + reuptake - reprocess;
+        if (w < 0.0) w = 0.0;
+        output[n] = hdt * c;
+    }
+}
+
+/* out is [64][L] int16: channel c's stream at out + c*L */
+int ora_subband64(const short *in, long L, short *out)
+{
+    float cf[NCHAN], bw[NCHAN], me[NCHAN];
+    float *input, *g, *h;
+    long n;
+    int c;
+    if (L <= 0) return 1;
+    ora_resynth_channels(cf, bw, me);
+    input = (float *)malloc(L * sizeof(float));
+    g = (float *)malloc(L * sizeof(float));
+    h = (float *)malloc(L * sizeof(float));
+    for (n = 0; n < L; n++) input[n] = (float)in[n];
+    for (c = 0; c < NCHAN; c++) {
+        ora_gammatone(input, g, cf[c], bw[c], me[c], L);
+        ora_haircell(g, h, L);
+        for (n = 0; n < L; n++) {
+            float v = h[n];
+            out[(long)c * L + n] = (v > -2147483648.0f && v < 2147483648.0f) ? (short)(int)v : 0;
+        }
+    }
+    free(input);
+    free(g);
+    free(h);
+    return 0;
+}

@@ -46,6 +46,11 @@ void ora_gammatone(const float *in, float *out, float cf, float bw, float midEar
 /* extractwav.cpp:41-54: per-channel constants cf, bw, midEarCoeff (64 each) */
 void ora_resynth_channels(float *cf64, float *bw64, float *midEar64);
 
+/* SURVEY 8(f) rank 1 -- subbband(): enhancement_extract_test/cpp/extractwav.cpp:40-101 and
+ * hairCell resyth_64sub_ori/cpp/extractwav.cpp:212-257.  out is [64][L].  Parity unpinned. */
+void ora_haircell(const float *input, float *output, long L);
+int ora_subband64(const short *in, long L, short *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -399,6 +399,44 @@ int sea_resynth_utterances(const short *const *in, const long *lengths, const fl
     return 0;
 }
 
+int sea_subband64_batch(const short *d_in, short *d_out, const long long *d_offsets, const long long *d_lengths,
+                        const int *d_order, int n_utt, void *stream)
+{
+    if (n_utt <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    sea::SubbandArgs a;
+    a.in = d_in;
+    a.out = d_out;
+    a.offsets = d_offsets;
+    a.lengths = d_lengths;
+    a.order = d_order;
+    a.tables = c->gt;
+    a.n_utt = n_utt;
+    hipLaunchKernelGGL(sea::subband_kernel, dim3(n_utt), dim3(320), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sea_subband64(const short *in, long L, short *out)
+{
+    if (L <= 0) return fail("subband64: L=%ld", L);
+    const long long Lp = align8(L);
+    DevBuf<short> din, dout;
+    DevBuf<long long> dmeta;
+    HIP_TRY(din.alloc((size_t)Lp));
+    HIP_TRY(dout.alloc((size_t)Lp * 64));
+    HIP_TRY(dmeta.alloc(2));
+    const long long meta[2] = {0, L};
+    HIP_TRY(hipMemcpy(din.p, in, (size_t)L * sizeof(short), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dmeta.p, meta, sizeof meta, hipMemcpyHostToDevice));
+    if (sea_subband64_batch(din.p, dout.p, dmeta.p, dmeta.p + 1, nullptr, 1, nullptr)) return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy2D(out, (size_t)L * sizeof(short), dout.p, (size_t)Lp * sizeof(short), (size_t)L * sizeof(short), 64,
+                        hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int sea_gammatone_filter(const float *input, float *output, int chan, long sigLength)
 {
     if (chan < 0 || chan >= 64) return fail("gammatone: channel %d out of range", chan);

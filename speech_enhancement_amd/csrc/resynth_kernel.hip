@@ -321,4 +321,160 @@ __global__ __launch_bounds__(192) void resynth_bwd_kernel(ResynthArgs a)
     }
 }
 
+/* ---- subbband() -- the analysis half on its own --------------------------------
+ * gammatone -> Meddis hair cell -> (short) cast -> 64 int16 streams per utterance
+ * (enhancement_extract_test/cpp/extractwav.cpp:40-101; hairCell resyth_64sub_ori/cpp/extractwav.cpp:
+ * 212-257, constants HuWang.h:36-44).  Output is 64x the input: 128 B written per input sample, the
+ * one genuinely HBM-write-heavy kernel of the path.  Workgroup = one utterance = five waves,
+ * lane = channel, 16-sample tiles:
+ *   R1, R2  the two halves of the gammatone cascade (as in the resynthesis kernels)
+ *   K       the hair cell's input-only permeability kt (a double division per sample)
+ *   HC      the q/c/w recurrence, output hdt*c truncated to int16 into a padded LDS tile
+ *   W       transposes the tile (lane = 16 samples x 4 channels) and streams 32-byte runs of each
+ *           channel's row; consecutive tiles complete the 128-byte lines in L2. */
+namespace {
+
+struct HairCell { /* Meddis 1988 constants as the reference's C++ evaluates them (float dt, double literals) */
+    float ymdt, xdt, ydt, lplusrdt, rdt, gdt, hdt;
+    float q, c, w;
+};
+
+__device__ __forceinline__ void haircell_init(HairCell &h)
+{
+    const double Y = 5.05, G = 2000.0, Lc = 2500.0, R = 6580.0, X = 66.31, A = 3.0, B = 300.0, H = 48000.0, M = 1.0;
+    const float dt = 1 / (float)16000;
+    h.ymdt = (float)(Y * M * dt);
+    h.xdt = (float)(X * dt);
+    h.ydt = (float)(Y * dt);
+    h.lplusrdt = (float)((Lc + R) * dt);
+    h.rdt = (float)(R * dt);
+    h.gdt = (float)(G * dt);
+    h.hdt = (float)H;
+    const float kt = (float)(G * A / (A + B));
+    h.c = (float)(M * Y * kt / (Lc * kt + Y * (Lc + R)));
+    h.q = (float)(h.c * (Lc + R) / kt);
+    h.w = (float)(h.c * R / X);
+}
+
+/* permeability of one sample (extractwav.cpp:237): depends on the input only */
+__device__ __forceinline__ float haircell_kt(const HairCell &h, float in)
+{
+    const double s = (double)in + 3.0;
+    return (s > 0.0) ? (float)((double)h.gdt * s / (s + 300.0)) : 0.0f;
+}
+
+/* the recurrence (extractwav.cpp:239-255); returns output[n] = hdt * c */
+__device__ __forceinline__ float haircell_step(HairCell &h, float kt)
+{
+    const float replenish = ((double)h.q < 1.0) ? (h.ymdt - h.ydt * h.q) : 0.0f;
+    const float eject = kt * h.q;
+    const float reuptakeandloss = h.lplusrdt * h.c;
+    const float reuptake = h.rdt * h.c;
+    const float reprocess = h.xdt * h.w;
+    h.q = h.q + replenish - eject + reprocess;
+    if (h.q < 0.0f) h.q = 0.0f;
+    h.c = h.c + eject - reuptakeandloss;
+    if (h.c < 0.0f) h.c = 0.0f;
+    h.w = h.w + reuptake - reprocess;
+    if (h.w < 0.0f) h.w = 0.0f;
+    return h.hdt * h.c;
+}
+
+constexpr int kSbStride = 66; /* int16 per tile row: 64 channels + 2 pad (33 words: conflict-free) */
+
+} // namespace
+
+__global__ __launch_bounds__(320) void subband_kernel(SubbandArgs a)
+{
+    __shared__ RsLds S;
+    __shared__ __attribute__((aligned(16))) float xs[kTile];
+    __shared__ __attribute__((aligned(16))) float ktile[2][kTile][64];
+    __shared__ __attribute__((aligned(16))) short otile[2][kTile * kSbStride];
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    const long long off = a.offsets[u], L = a.lengths[u];
+    const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 4;
+    if (role == 0) {
+        const int16_t *in = a.in + off;
+        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane];
+        GtLo s = {0, 0, 0, 0};
+        float xnext = (lane < kTile && lane < L) ? (float)in[lane] : 0.0f;
+        for (long long j = 0; j < niter; ++j) {
+            if (j < ntile) {
+                if (lane < kTile) xs[lane] = xnext;
+                const long long nn = (j + 1) * kTile + lane;
+                if (lane < kTile) xnext = (nn < L) ? (float)in[nn] : 0.0f;
+                wave_sync();
+                float2(*o)[64] = S.pq[j & 1];
+#pragma unroll
+                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_lo(s, xs[t], f1, f2);
+                wave_sync();
+            }
+            tile_sync();
+        }
+    } else if (role == 1) {
+        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane], gain = a.tables->gain[lane];
+        GtHi s = {0, 0, 0, 0, 0, 0};
+        for (long long j = 0; j < niter; ++j) {
+            const long long jt = j - 1;
+            if (jt >= 0 && jt < ntile) {
+                const float2(*i)[64] = S.pq[jt & 1];
+                float(*o)[64] = S.g[jt & 1];
+#pragma unroll
+                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_hi(s, i[t][lane], f1, f2, gain);
+            }
+            tile_sync();
+        }
+    } else if (role == 2) {
+        /* K: the hair cell's permeability, input-only (16 independent double divisions per tile) */
+        HairCell h;
+        haircell_init(h);
+        for (long long j = 0; j < niter; ++j) {
+            const long long jt = j - 2;
+            if (jt >= 0 && jt < ntile) {
+                const float(*g)[64] = S.g[jt & 1];
+                float(*o)[64] = ktile[jt & 1];
+#pragma unroll
+                for (int t = 0; t < kTile; ++t) o[t][lane] = haircell_kt(h, g[t][lane]);
+            }
+            tile_sync();
+        }
+    } else if (role == 3) {
+        /* HC: the q/c/w recurrence and the (short) cast of hOut (extractwav.cpp:85-88) */
+        HairCell h;
+        haircell_init(h);
+        for (long long j = 0; j < niter; ++j) {
+            const long long jt = j - 3;
+            if (jt >= 0 && jt < ntile) {
+                const float(*k)[64] = ktile[jt & 1];
+                short *o = otile[jt & 1];
+#pragma unroll
+                for (int t = 0; t < kTile; ++t) o[t * kSbStride + lane] = (short)cast_i16(haircell_step(h, k[t][lane]));
+            }
+            tile_sync();
+        }
+    } else {
+        /* W: lane = sample t (0..15) of channel group cg (0..3): 16 passes cover the 64 channels */
+        int16_t *out = a.out + off * 64;
+        const long long Lp = (L + 7) & ~7LL; /* row pitch of this utterance's [64][Lp] block */
+        const int t = lane & 15, cg = lane >> 4;
+        for (long long j = 0; j < niter; ++j) {
+            const long long jt = j - 4;
+            if (jt >= 0 && jt < ntile) {
+                const long long n = jt * kTile + t;
+                const short *o = otile[jt & 1] + t * kSbStride;
+                if (n < L) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int c = 4 * k + cg;
+                        out[c * Lp + n] = o[c];
+                    }
+                }
+            }
+            tile_sync();
+        }
+    }
+}
+
 } // namespace sea

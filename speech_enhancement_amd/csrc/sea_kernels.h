@@ -61,6 +61,19 @@ struct ResynthArgs {
     int binary;
 };
 
+/* subbband(): utterance u's 64 int16 streams form a [64][pitch] block at out + offsets[u]*64,
+ * pitch = lengths[u] rounded up to 8 samples */
+struct SubbandArgs {
+    const int16_t *in;
+    int16_t *out;
+    const long long *offsets;
+    const long long *lengths;
+    const int *order;
+    const sea_gt_tables *tables;
+    int n_utt;
+};
+
+__global__ void subband_kernel(SubbandArgs a);
 __global__ void ns_denoise_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_kernel(NsBatchArgs a);
 __global__ void ns_stream_kernel(NsStreamArgs a);

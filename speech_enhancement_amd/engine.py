@@ -68,6 +68,15 @@ def resynth(x, mask, binary=False):
     return out
 
 
+def subbband(x):
+    """subbband(): x int16[L] -> int16[64][L] (gammatone + hair cell per channel)."""
+    lib = _lib.load()
+    x = np.ascontiguousarray(x, dtype=np.int16)
+    out = np.zeros((64, x.size), np.int16)
+    _lib.check(lib.sea_subband64(_np_ptr(x), x.size, _np_ptr(out)), "subbband")
+    return out
+
+
 def gammaToneFilter(x, chan):
     lib = _lib.load()
     x = np.ascontiguousarray(x, dtype=np.float32)
@@ -293,6 +302,19 @@ def resynth_batch(batch, masks, binary=False, out=None, scratch=None, use_order=
                                  _stream_ptr())
     _lib.check(rc, "sea_resynth64_batch")
     return out, scratch
+
+
+def subband_batch(batch, out=None, use_order=True):
+    """subbband() for every utterance of the batch.  Returns an int16 tensor of 64x the packed
+    size: utterance u's [64][pitch] block starts at offsets[u]*64, pitch = length rounded up to 8."""
+    torch = _torch()
+    lib = _lib.load()
+    if out is None:
+        out = torch.zeros(batch.total * 64, dtype=torch.int16, device=batch.data.device)
+    rc = lib.sea_subband64_batch(_dptr(batch.data), _dptr(out), _dptr(batch.offsets), _dptr(batch.lengths),
+                                 _dptr(batch.order) if use_order else None, batch.n_utt, _stream_ptr())
+    _lib.check(rc, "sea_subband64_batch")
+    return out
 
 
 def ns_streams_push(frames, state=None, reset=None):

@@ -365,3 +365,27 @@ def _ln_ratio(x):
     out = np.zeros(q32.size, np.float64)
     assert sea.load().sea_selftest_log(q32.ctypes.data, out.ctypes.data, q32.size) == 0
     return out
+
+
+def test_subband_vs_oracle(oracle):
+    """subbband(): gammatone + Meddis hair cell + (short) cast -> 64 int16 streams.
+    The oracle for this function is parity-unpinned (no reference build, no recorded output); the
+    GPU must equal it bit for bit."""
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    torch = _torch()
+    lens = [4800, 1600 + 77, 1, 17, 16, 8000]
+    utts = [corpus.synth_utterance(80 + i, L) for i, L in enumerate(lens)]
+    batch = sea.PackedBatch.from_arrays(utts)
+    out = sea.subband_batch(batch)
+    torch.cuda.synchronize()
+    host = out.cpu().numpy()
+    for u, x in enumerate(utts):
+        L = len(x)
+        pitch = (L + 7) // 8 * 8
+        blk = host[batch.host_offsets[u] * 64: batch.host_offsets[u] * 64 + 64 * pitch].reshape(64, pitch)
+        want = oracle.subband64(x)
+        assert np.array_equal(blk[:, :L], want), f"utt {u} (L={L})"
+    one = sea.subbband(utts[0])
+    assert np.array_equal(one, oracle.subband64(utts[0]))
+    assert one.min() >= 0 and one.max() > 100      # hair-cell output is a non-negative firing rate

@@ -40,7 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--utts", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--what", default="resynth,ibm,ceps,rfft")
+    ap.add_argument("--what", default="resynth,ibm,subband,ceps,rfft")
     args = ap.parse_args()
     import torch
     import speech_enhancement_amd as sea
@@ -72,6 +72,20 @@ def main():
                              "intermediate_bytes_per_step": int(batch.total) * 64 * 4 * 2,
                              "intermediate_GBps": int(batch.total) * 64 * 4 * 2 / ker / 1e9, "avg_step_ms": ker * 1e3}}),
                   flush=True)
+
+    if "subband" in what:
+        out = torch.zeros(batch.total * 64, dtype=torch.int16, device=dev)
+        wall, ker = timed(lambda: sea.subband_batch(batch, out=out), args.steps)
+        samples = int(np.sum(batch.host_lengths))
+        alg = samples * (2 + 128)
+        print(json.dumps({
+            "metric": "subbband() samples/sec (gammatone + hair cell -> 64 int16 streams)", "value": samples / wall,
+            "unit": "samples/s", "ms_per_step": wall * 1e3, "rtf": wall / audio_s,
+            "config": {"workload": f"SURVEY 8(f) #1: {args.utts} utterances, 64-channel analysis to 64 int16 streams"},
+            "roofline": {"bound": "hbm", "kernel": "sea::subband_kernel", "achieved": alg / ker / 1e9,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / ker / 1e9 / HBM_PEAK_GBPS,
+                         "algorithmic_bytes_per_step": alg, "avg_step_ms": ker * 1e3}}), flush=True)
+        del out
 
     if "ceps" in what:
         out, f32, first = sea.ns_denoise_batch(batch, want_f32=True)
