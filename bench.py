@@ -205,7 +205,7 @@ def main():
                 "avg_launch_ms": avg_kernel_s * 1e3,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N=1 only
             base, outs = cpu_baseline(batch, args.cpu_utts, args.cpu_threads)
             result["cpu_baseline"] = base
             # parity spot check on the sample (the oracle as checker, never as the measured path)

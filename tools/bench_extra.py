@@ -40,7 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--utts", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--what", default="resynth,ibm,subband,ceps,rfft")
+    ap.add_argument("--what", default="resynth,ibm,subband,ceps,rfft,host")
     args = ap.parse_args()
     import torch
     import speech_enhancement_amd as sea
@@ -103,6 +103,27 @@ def main():
                           "roofline": {"bound": "hbm", "kernel": "sea::compceps_kernel", "achieved": alg / ker / 1e9,
                                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / ker / 1e9 / HBM_PEAK_GBPS,
                                        "algorithmic_bytes_per_step": alg, "avg_step_ms": ker * 1e3}}), flush=True)
+
+    if "host" in what:
+        # the host-buffer drop-in path: pack + hipMalloc + H2D + one launch + D2H (PCIe inclusive)
+        import ctypes
+        lib = sea.load()
+        host = batch.data.cpu().numpy()
+        ins = [np.ascontiguousarray(host[o:o + l]) for o, l in zip(batch.host_offsets, batch.host_lengths)]
+        outs = [np.zeros_like(x) for x in ins]
+        n = len(ins)
+        pin = (ctypes.c_void_p * n)(*[x.ctypes.data for x in ins])
+        pout = (ctypes.c_void_p * n)(*[x.ctypes.data for x in outs])
+        lens = (ctypes.c_long * n)(*[x.size for x in ins])
+        lib.sea_denoise_utterances(pin, pout, lens, n)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            assert lib.sea_denoise_utterances(pin, pout, lens, n) == 0
+        wall = (time.perf_counter() - t0) / args.steps
+        print(json.dumps({"metric": "NoiseSup frames/sec through the HOST-buffer entry point (PCIe inclusive)",
+                          "value": batch.n_frames / wall, "unit": "frames/s", "ms_per_step": wall * 1e3,
+                          "config": {"workload": f"sea_denoise_utterances on {n} host utterances: pack, hipMalloc, "
+                                                 "H2D, one launch, D2H, unpack"}}), flush=True)
 
     if "rfft" in what:
         n = 1 << 18
