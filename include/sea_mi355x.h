@@ -88,12 +88,14 @@ int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const
                        float *d_ceps, int *d_n_ceps, int n_utt, void *stream);
 /* 64-band gammatone resynthesis over a batch.  mask rows (64 floats) of utterance u start at row
  * d_mask_offsets[u] and number (lengths[u]-320)/160+1.  d_inter is scratch of
- * sea_resynth_scratch_bytes() bytes.  binary != 0 selects the ideal-binary-mask variant. */
+ * sea_resynth_scratch_bytes(total padded samples of the batch, n_utt) bytes (the [time][64]
+ * float intermediate between the two passes, ~256 B per sample: it is what 288 GB of HBM is
+ * for).  binary != 0 selects the ideal-binary-mask variant. */
 int sea_resynth64_batch(const short *d_in, short *d_out, const long long *d_offsets,
                         const long long *d_lengths, const float *d_mask,
                         const long long *d_mask_offsets, float *d_inter, const int *d_order,
                         int n_utt, int binary, void *stream);
-long long sea_resynth_scratch_bytes(long long total_padded_samples);
+long long sea_resynth_scratch_bytes(long long total_padded_samples, int n_utt);
 
 /* ----------------------------------------------------------------------------------------------
  * (2) handle-based plug-in equivalents and host-buffer conveniences
@@ -140,6 +142,10 @@ int sea_ns_state_floats(void);
  * -------------------------------------------------------------------------------------------- */
 /* all 2^32 floats s: (float)((double)s * (1/sqrt2)) vs (float)((double)s / sqrt2); count of differences */
 int sea_selftest_pi4(unsigned long long *n_mismatch);
+/* the resynthesis kernels' 3-instruction division by the per-channel middle-ear gain: every float
+ * inside its domain (2^-100 <= |a| <= 2^100) x all 64 divisors against the IEEE quotient.
+ * out2[0] = mismatches, out2[1] = patterns tested per divisor */
+int sea_selftest_div(unsigned long long *out2);
 /* DC-offset recurrence on ncases frames of 80 differences (host pointers): output and whether the
  * exact double path had to be taken */
 int sea_selftest_dc(const float *dif, const float *y0, float *out, int *fellback, int ncases);

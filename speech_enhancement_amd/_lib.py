@@ -31,7 +31,7 @@ PROTOTYPES = {
     "sea_compceps_frames": (_i, [_vp, _vp, _ll, _vp]),
     "sea_compceps_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _vp]),
     "sea_resynth64_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "sea_resynth_scratch_bytes": (_ll, [_ll]),
+    "sea_resynth_scratch_bytes": (_ll, [_ll, _i]),
     "sea_denoise_utterances": (_i, [_vp, _vp, _vp, _i]),
     "sea_compceps_frame": (_i, [_vp, _vp]),
     "sea_resynth64": (_i, [_vp, _l, _vp, _i, _i, _vp]),
@@ -46,6 +46,7 @@ PROTOTYPES = {
     "sea_ns_streams_push": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sea_ns_state_floats": (_i, []),
     "sea_selftest_pi4": (_i, [_vp]),
+    "sea_selftest_div": (_i, [_vp]),
     "sea_selftest_dc": (_i, [_vp, _vp, _vp, _vp, _i]),
     "sea_selftest_log": (_i, [_vp, _vp, _i]),
 }

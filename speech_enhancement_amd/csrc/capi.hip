@@ -300,9 +300,9 @@ int sea_compceps_frame(const float *Data, float *Coef14)
 }
 
 /* ------------------------------------------------------------------------------------------- */
-long long sea_resynth_scratch_bytes(long long total_padded_samples)
-{
-    return total_padded_samples * 64 * (long long)sizeof(float);
+long long sea_resynth_scratch_bytes(long long total_padded_samples, int n_utt)
+{ /* [sample][64] floats, plus 8 time steps per utterance for rounding up to whole 16-step tiles */
+    return (total_padded_samples + 8LL * (n_utt > 0 ? n_utt : 0)) * 64 * (long long)sizeof(float);
 }
 
 int sea_resynth64_batch(const short *d_in, short *d_out, const long long *d_offsets,
@@ -327,7 +327,7 @@ int sea_resynth64_batch(const short *d_in, short *d_out, const long long *d_offs
     a.binary = binary;
     hipLaunchKernelGGL(sea::resynth_fwd_kernel, dim3(n_utt), dim3(192), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(sea::resynth_bwd_kernel, dim3(n_utt), dim3(192), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(sea::resynth_bwd_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -343,7 +343,7 @@ int sea_resynth64(const short *in, long L, const float *mask, int F, int binary,
     HIP_TRY(din.alloc((size_t)Lp));
     HIP_TRY(dout.alloc((size_t)Lp));
     HIP_TRY(dmask.alloc((size_t)F * 64));
-    HIP_TRY(dinter.alloc((size_t)Lp * 64));
+    HIP_TRY(dinter.alloc((size_t)sea_resynth_scratch_bytes(Lp, 1) / sizeof(float)));
     HIP_TRY(dmeta.alloc(3));
     const long long meta[3] = {0, L, 0};
     HIP_TRY(hipMemcpy(din.p, in, (size_t)L * sizeof(short), hipMemcpyHostToDevice));
@@ -383,7 +383,7 @@ int sea_resynth_utterances(const short *const *in, const long *lengths, const fl
     HIP_TRY(din.alloc((size_t)total));
     HIP_TRY(dout.alloc((size_t)total));
     HIP_TRY(dmask.alloc(mpack.size()));
-    HIP_TRY(dinter.alloc((size_t)total * 64));
+    HIP_TRY(dinter.alloc((size_t)sea_resynth_scratch_bytes(total, n_utt) / sizeof(float)));
     HIP_TRY(dmeta.alloc(3 * (size_t)n_utt));
     HIP_TRY(hipMemcpy(din.p, pack.data(), (size_t)total * sizeof(short), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dmask.p, mpack.data(), mpack.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -555,6 +555,20 @@ int sea_selftest_pi4(unsigned long long *n_mismatch)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(n_mismatch, d.p, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sea_selftest_div(unsigned long long *out2)
+{
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    DevBuf<unsigned long long> d;
+    HIP_TRY(d.alloc(2));
+    HIP_TRY(hipMemset(d.p, 0, 2 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(sea::selftest_div_kernel, dim3(4096), dim3(256), 0, nullptr, c->gt, d.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out2, d.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

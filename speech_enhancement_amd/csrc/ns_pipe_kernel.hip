@@ -43,6 +43,37 @@ constexpr int kPipeWaves = 4;
 #define SEA_ROLE_MASK 127
 #endif
 
+
+/* timing-only diagnostic (-DSEA_NS_TIMING): shader-clock cycles each role of workgroup 0 spends
+ * working / waiting at the frame barrier -> g_ns_timing[role*2 + {0,1}] */
+#ifdef SEA_NS_TIMING
+__device__ unsigned long long g_ns_timing[8];
+struct RoleTimer {
+    unsigned long long work = 0, wait = 0, t0 = 0, t1 = 0;
+    __device__ __forceinline__ void begin() { t0 = clock64(); }
+    __device__ __forceinline__ void mid() { t1 = clock64(); work += t1 - t0; }
+    __device__ __forceinline__ void end() { wait += clock64() - t1; }
+    __device__ __forceinline__ void flush(int slot)
+    {
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+            g_ns_timing[slot] = work;
+            g_ns_timing[slot + 1] = wait;
+        }
+    }
+};
+#define NS_T_DECL RoleTimer rt_
+#define NS_T_BEGIN rt_.begin()
+#define NS_T_MID rt_.mid()
+#define NS_T_END rt_.end()
+#define NS_T_FLUSH(slot) rt_.flush(slot)
+#else
+#define NS_T_DECL
+#define NS_T_BEGIN
+#define NS_T_MID
+#define NS_T_END
+#define NS_T_FLUSH(slot)
+#endif
+
 struct __attribute__((aligned(16))) Rec01 { /* F -> B0, S */
     float psd[68];
     int valid, tick, pad0, pad1;
@@ -136,6 +167,7 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
     }
     block_sync();
 
+    NS_T_DECL;
     if (role == 0) {
         /* ---- F: input + zero-frame gate (ParmInterface.c:244-251); front halves of both stages ---- */
         Fft2Regs fft;
@@ -148,6 +180,7 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
         uint32_t nextw = (lane < 40 && nfr > 0) ? in32[lane] : 0u;
         int tick = 0; /* frames seen since (and including) the first non-zero one */
         for (long long i = 0; i < niter; ++i) {
+            NS_T_BEGIN;
             /* stage 0, frame i */
             bool actA = false;
             Rec01 &rA = L.r01[i & 1];
@@ -189,8 +222,11 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                 ns_front_dual(L.circ[0] + window_base(tick), actA, rA.psd, L.circ[1] + window_base(tB), actB, rB.psd,
                               L.work, fft, flags, win, lane);
             }
+            NS_T_MID;
             block_sync();
+            NS_T_END;
         }
+        NS_T_FLUSH(0);
     } else if (role == 1) {
         /* ---- B0: BACK of stage 0; its 80 outputs enter the stage-1 buffer ---- */
         NsConst C;
@@ -198,6 +234,7 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
         NsRegs s;
         regs_init(s, C.eps);
         for (long long i = 0; i < niter; ++i) {
+            NS_T_BEGIN;
             const long long f = i - 1;
             if (f >= 0 && f < nfr) {
                 const Rec01 &r = L.r01[f & 1];
@@ -217,8 +254,11 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                     o.tick = t;
                 }
             }
+            NS_T_MID;
             block_sync();
+            NS_T_END;
         }
+        NS_T_FLUSH(2);
     } else if (role == 2) {
         /* ---- B1: BACK of stage 1 ---- */
         NsConst C;
@@ -226,6 +266,7 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
         NsRegs s;
         regs_init(s, C.eps);
         for (long long i = 0; i < niter; ++i) {
+            NS_T_BEGIN;
             const long long f = i - 3;
             if (f >= 0 && f < nfr) {
                 const Rec23 &r = L.r23[f & 1];
@@ -243,8 +284,11 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                 }
                 if (lane == 0) o.produced = produced;
             }
+            NS_T_MID;
             block_sync();
+            NS_T_END;
         }
+        NS_T_FLUSH(4);
     } else {
         /* ---- S: scalar chains ---- */
         uint32_t *out32 = reinterpret_cast<uint32_t *>(a.out + off);
@@ -252,6 +296,7 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
         float dcX = 0.0f, dcY = 0.0f; /* prevSamples, NoiseSup.c:908-909 */
         int firstOut = -1;
         for (long long i = 0; i < niter; ++i) {
+            NS_T_BEGIN;
             /* (1) VAD log-energy (NoiseSup.c:386-391) of the frame pushed at i-1 = tick tp; it is
              *     the "current frame" buf[80..159] of tick tp+2 */
             const long long fp = i - 1;
@@ -305,10 +350,20 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                 }
                 wave_sync();
             }
+            NS_T_MID;
             block_sync();
+            NS_T_END;
         }
         if (a.first_out && lane == 0) a.first_out[u] = firstOut;
+        NS_T_FLUSH(6);
     }
 }
 
 } // namespace sea
+
+#ifdef SEA_NS_TIMING
+extern "C" int sea_debug_ns_timing(unsigned long long *out8)
+{
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(sea::g_ns_timing), 8 * sizeof(unsigned long long));
+}
+#endif

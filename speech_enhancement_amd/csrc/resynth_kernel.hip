@@ -36,66 +36,96 @@ namespace sea {
 
 namespace {
 
-struct GtState {
-    float p0, p1, p2, p3, q0, q1, q2, q3;
-};
+/* timing-only diagnostic: bit k set = role k of the tile pipelines skips its work (results wrong) */
+#ifndef SEA_RS_SKIP
+#define SEA_RS_SKIP 0
+#endif
 
-/* one sample of gammaToneFilter (extractwav.cpp:188-210); returns output[n] = p[3]*gain taken
- * BEFORE the update */
-__device__ __forceinline__ float gt_step(GtState &s, float in, float f1, float f2, float gain)
+/* timing-only diagnostic (-DSEA_RS_TIMING): per role, shader-clock cycles spent working and waiting
+ * at the tile barrier, for workgroup 0 -> g_rs_timing[kernel*6 + role*2 + {0,1}] */
+#ifdef SEA_RS_TIMING
+__device__ unsigned long long g_rs_timing[16]; /* fwd R1,R2,H = 0..5; bwd R1,R2,W,SUM = 6..13 */
+struct RoleTimer {
+    unsigned long long work = 0, wait = 0, t0 = 0, t1 = 0;
+    __device__ __forceinline__ void begin() { t0 = clock64(); }
+    __device__ __forceinline__ void mid() { t1 = clock64(); work += t1 - t0; }
+    __device__ __forceinline__ void end() { wait += clock64() - t1; }
+    __device__ __forceinline__ void flush(int slot)
+    {
+        if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {
+            g_rs_timing[slot] = work;
+            g_rs_timing[slot + 1] = wait;
+        }
+    }
+};
+#define RS_T_DECL RoleTimer rt_
+#define RS_T_BEGIN rt_.begin()
+#define RS_T_MID rt_.mid()
+#define RS_T_END rt_.end()
+#define RS_T_FLUSH(slot) rt_.flush(slot)
+#else
+#define RS_T_DECL
+#define RS_T_BEGIN
+#define RS_T_MID
+#define RS_T_END
+#define RS_T_FLUSH(slot)
+#endif
+
+/* One sample of gammaToneFilter (extractwav.cpp:188-210) is
+ *     out = p3*gain (taken BEFORE the update);  x_k = f1 p_k - f2 q_k,  y_k = f2 p_k + f1 q_k;
+ *     p0 = in*f1 + x0;  p1 = p0 + x1;  p2 = p1 + x1 + x2;  p3 = p2 + x1 + 2 x2 + x3   (q alike with y).
+ * It is evaluated in two halves (stages 0-1, stages 2-3) so that two waves can pipeline it. */
+
+/* Both halves work on PACKED pairs: the state of cascade stage k is the pair (p_k, q_k) and
+ * every operation of the reference acts on p and q alike, so each pair lives in an even-aligned
+ * VGPR pair and is advanced by v_pk_mul_f32 / v_pk_add_f32 (two IEEE float operations per
+ * instruction, individually rounded exactly like v_mul_f32 / v_add_f32; -ffp-contract=off keeps
+ * them unfused).  The rotation  x = f1 p - f2 q,  y = f2 p + f1 q  becomes
+ *     (f1,f1)*(p,q) + (-f2,f2)*(q,p)
+ * -- negating f2 is exact and float addition commutes, so x and y are bit-identical to the
+ * reference's expressions; the (q,p) swap is an operand select of the packed instruction.  This
+ * halves the vector instructions of the recurrence (22 instead of 43 per sample and channel). */
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct GtCoef {
+    v2f f11, nf2, f12; /* (f1,f1), (-f2,f2), (f1,f2) */
+};
+__device__ __forceinline__ GtCoef gt_coef(float f1, float f2)
 {
-    const float out = s.p3 * gain;
-    const float x0 = f1 * s.p0 - f2 * s.q0, y0 = f2 * s.p0 + f1 * s.q0;
-    const float x1 = f1 * s.p1 - f2 * s.q1, y1 = f2 * s.p1 + f1 * s.q1;
-    const float x2 = f1 * s.p2 - f2 * s.q2, y2 = f2 * s.p2 + f1 * s.q2;
-    const float x3 = f1 * s.p3 - f2 * s.q3, y3 = f2 * s.p3 + f1 * s.q3;
-    s.p0 = in * f1 + x0;
-    s.q0 = in * f2 + y0;
-    s.p1 = s.p0 + x1;
-    s.q1 = s.q0 + y1;
-    s.p2 = s.p1 + x1 + x2;
-    s.q2 = s.q1 + y1 + y2;
-    s.p3 = s.p2 + x1 + 2 * x2 + x3;
-    s.q3 = s.q2 + y1 + 2 * y2 + y3;
-    return out;
+    GtCoef c;
+    c.f11 = v2f{f1, f1};
+    c.nf2 = v2f{-f2, f2};
+    c.f12 = v2f{f1, f2};
+    return c;
 }
+__device__ __forceinline__ v2f gt_rot(const GtCoef &c, v2f s) { return c.f11 * s + c.nf2 * s.yx; }
 
-/* The same step cut in two.  Stages 0-1: consumes the input sample, returns the NEW (p1,q1). */
+/* Stages 0-1: consumes the input sample, returns the NEW (p1,q1). */
 struct GtLo {
-    float p0, q0, p1, q1;
+    v2f s0, s1;
 };
-__device__ __forceinline__ float2 gt_step_lo(GtLo &s, float in, float f1, float f2)
+__device__ __forceinline__ v2f gt_step_lo(GtLo &s, float in, const GtCoef &c)
 {
-    const float x0 = f1 * s.p0 - f2 * s.q0, y0 = f2 * s.p0 + f1 * s.q0;
-    const float x1 = f1 * s.p1 - f2 * s.q1, y1 = f2 * s.p1 + f1 * s.q1;
-    s.p0 = in * f1 + x0;
-    s.q0 = in * f2 + y0;
-    s.p1 = s.p0 + x1;
-    s.q1 = s.q0 + y1;
-    return make_float2(s.p1, s.q1);
+    const v2f r0 = gt_rot(c, s.s0), r1 = gt_rot(c, s.s1);
+    s.s0 = v2f{in, in} * c.f12 + r0; /* p0 = in*f1 + x0, q0 = in*f2 + y0 */
+    s.s1 = s.s0 + r1;
+    return s.s1;
 }
 /* Stages 2-3: needs the new (p1,q1) and x1,y1 -- the rotation of the OLD (p1,q1), which this wave
- * kept from the previous sample, so the same two products and one add/sub reproduce them exactly. */
+ * kept from the previous sample, so the same products and sum reproduce them exactly. */
 struct GtHi {
-    float p1old, q1old, p2, q2, p3, q3;
+    v2f s1old, s2, s3;
 };
-__device__ __forceinline__ float gt_step_hi(GtHi &s, float2 pq1, float f1, float f2, float gain)
+__device__ __forceinline__ float gt_step_hi(GtHi &s, v2f pq1, const GtCoef &c, float gain)
 {
-    const float out = s.p3 * gain;
-    const float x1 = f1 * s.p1old - f2 * s.q1old, y1 = f2 * s.p1old + f1 * s.q1old;
-    const float x2 = f1 * s.p2 - f2 * s.q2, y2 = f2 * s.p2 + f1 * s.q2;
-    const float x3 = f1 * s.p3 - f2 * s.q3, y3 = f2 * s.p3 + f1 * s.q3;
-    s.p2 = pq1.x + x1 + x2;
-    s.q2 = pq1.y + y1 + y2;
-    s.p3 = s.p2 + x1 + 2 * x2 + x3;
-    s.q3 = s.q2 + y1 + 2 * y2 + y3;
-    s.p1old = pq1.x;
-    s.q1old = pq1.y;
+    const float out = s.s3.x * gain;
+    const v2f r1 = gt_rot(c, s.s1old), r2 = gt_rot(c, s.s2), r3 = gt_rot(c, s.s3);
+    s.s2 = pq1 + r1 + r2;
+    s.s3 = s.s2 + r1 + 2.0f * r2 + r3;
+    s.s1old = pq1;
     return out;
 }
 
-constexpr int kTile = 16;        /* time steps per hand-over between the pipelined waves */
-constexpr int kTileStride = 65;  /* 64 channels + 1 pad: conflict-free row reads by lane = sample */
 
 /* workgroup barrier for the role-specialised waves (same count, different program counters);
  * LDS-only fences: HBM loads and stores stay in flight across it */
@@ -106,14 +136,130 @@ __device__ __forceinline__ void tile_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+constexpr int kTile = 16;        /* time steps per hand-over between the pipelined waves */
+constexpr int kMacro = 2;        /* tiles per HBM request group of the synthesis pass */
+constexpr int kTileStride = 68;  /* floats per step in the padded tile: 64 channels + 4 (rows stay 16-byte aligned
+                                  * and 16 lanes reading 16 different rows as float4 hit 64 different banks) */
+
+/* ---- division by the per-channel middle-ear gain ------------------------------------------------
+ * Both passes divide every sample of every channel by midEar[c] (extractwav.cpp:86-90).  An IEEE
+ * float division expands to ~10 instructions; with the divisor a per-lane constant d and
+ * y = RN(1/d) computed once,
+ *     q = RN(a y);  r = RN(a - q d) (exact, one fma);  q' = RN(q + r y)
+ * returns RN(a/d) (Markstein's correction step) as long as nothing underflows.  This is not taken
+ * on faith: sea_selftest_div() runs all 2^32 float patterns of a through it for each of the 64
+ * divisors and compares with the hardware-correct a/d bit for bit; the kernels use it only inside
+ * the verified domain 2^-100 <= |a| <= 2^100 (checked per tile with one min3 and one max3 per two
+ * samples) and redo a tile with true divisions otherwise (zeros, denormal filter tails). */
+struct DivConst {
+    float d, y;
+};
+__device__ __forceinline__ DivConst div_const(float d)
+{
+    DivConst c;
+    c.d = d;
+    c.y = 1.0f / d;
+    return c;
+}
+__device__ __forceinline__ float div_fast(float a, const DivConst &c)
+{
+    const float q = a * c.y;
+    const float r = __fmaf_rn(-q, c.d, a);
+    return __fmaf_rn(r, c.y, q);
+}
+__device__ __forceinline__ v2f div_fast2(v2f a, const DivConst &c)
+{
+    const v2f y = {c.y, c.y}, nd = {-c.d, -c.d};
+    const v2f q = a * y;
+    const v2f r = __builtin_elementwise_fma(q, nd, a);
+    return __builtin_elementwise_fma(r, y, q);
+}
+constexpr float kDivLo = 0x1p-100f, kDivHi = 0x1p100f;
+__device__ __forceinline__ bool div_in_domain(float a)
+{
+    const float aa = fabsf(a);
+    return aa >= kDivLo && aa <= kDivHi;
+}
+
+/* 16 steps of one channel divided by its constant: packed fast path, with the domain check folded
+ * into one v_max3 / v_min3 per pair (inline asm: the |x| operand modifiers are free, and the
+ * library fmaxf would add a canonicalisation per operand); the whole wave redoes the tile with true
+ * divisions if any lane has a sample outside the verified domain (wave-uniform, rare). */
+__device__ __forceinline__ void div_tile16(const float (&g)[kTile], float (&v)[kTile], const DivConst &c)
+{
+    float mx = 0.0f, mn = kDivHi;
+#pragma unroll
+    for (int k = 0; k < kTile; k += 2) {
+        const v2f q = div_fast2(v2f{g[k], g[k + 1]}, c);
+        v[k] = q.x;
+        v[k + 1] = q.y;
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(mx) : "v"(mx), "v"(g[k]), "v"(g[k + 1]));
+        asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(mn) : "v"(mn), "v"(g[k]), "v"(g[k + 1]));
+    }
+    const bool outside = !(mn >= kDivLo && mx <= kDivHi);
+    if (__ballot(outside) != 0ull) {
+#pragma unroll
+        for (int k = 0; k < kTile; ++k) v[k] = g[k] / c.d;
+    }
+}
+
+/* int16 input of one utterance for the R1 wave (lane = channel needs every sample broadcast): one
+ * coalesced 128-byte request fetches a CHUNK of 64 samples = 4 tiles, raw, three chunks ahead of
+ * use, so that no HBM latency is ever waited for inside the per-tile loop (the loads are
+ * unconditional -- clamped address, value selected afterwards -- because a load under a branch
+ * gets its s_waitcnt at the end of that branch). */
+struct InFeed {
+    int c0, c1, c2; /* raw samples of chunks q, q+1, q+2 (this lane's sample of each) */
+    static __device__ __forceinline__ int fetch(const int16_t *in, long long L, long long chunk, int lane)
+    {
+        long long i = chunk * 64 + lane;
+        i = (i < L) ? i : L - 1;
+        return (int)in[i];
+    }
+    __device__ __forceinline__ void start(const int16_t *in, long long L, int lane)
+    {
+        c0 = c1 = c2 = 0;
+        if (L > 0) {
+            c0 = fetch(in, L, 0, lane);
+            c1 = fetch(in, L, 1, lane);
+            c2 = fetch(in, L, 2, lane);
+        }
+    }
+    /* deposit the 16 samples of tile j in xs[0..15] (zeros beyond L); L > 0 here */
+    __device__ __forceinline__ void tile(const int16_t *in, long long L, long long j, int lane, float *xs)
+    {
+        const int q = (int)(j & 3);
+        if (q == 0 && j > 0) {
+            c0 = c1;
+            c1 = c2;
+            c2 = fetch(in, L, (j >> 2) + 2, lane);
+        }
+        if ((lane >> 4) == q) {
+            const long long n = j * kTile + (lane & 15);
+            xs[lane & 15] = (n < L) ? (float)c0 : 0.0f;
+        }
+    }
+};
+
+/* HBM intermediate between the analysis and the synthesis pass: per utterance ntile = ceil(L/16)
+ * tiles of 16 time steps x 64 channels, tile = 4 KB = four 1 KB quarters, quarter k holding steps
+ * 4k..4k+3 of every channel as one float4 per lane (lane = channel).  Both passes move a tile with
+ * four wave-wide 16-byte-per-lane accesses, each of them one fully contiguous kilobyte.  Utterance
+ * u starts at float (offsets[u] + 8u) * 64: offsets are multiples of 8 samples, so the extra 8
+ * steps per utterance make room for rounding L up to whole tiles (sea_resynth_scratch_bytes). */
+__device__ __forceinline__ float *inter_base(float *inter, long long off, int u)
+{
+    return inter + (off + 8LL * u) * 64;
+}
+
 struct __attribute__((aligned(16))) RsLds {
-    float2 pq[2][kTile][64]; /* R1 -> R2 */
+    v2f pq[2][kTile][64];  /* R1 -> R2 */
     float g[2][kTile][64];   /* R2 -> H  */
 };
 
 } // namespace
 
-__global__ __launch_bounds__(192) void resynth_fwd_kernel(ResynthArgs a)
+__global__ __launch_bounds__(192, 3) void resynth_fwd_kernel(ResynthArgs a)
 {
     __shared__ RsLds S;
     __shared__ __attribute__((aligned(16))) float xs[kTile];
@@ -122,56 +268,72 @@ __global__ __launch_bounds__(192) void resynth_fwd_kernel(ResynthArgs a)
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long off = a.offsets[u], L = a.lengths[u];
     const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 2;
+    RS_T_DECL;
     if (role == 0) {
         const int16_t *in = a.in + off;
-        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane];
-        GtLo s = {0, 0, 0, 0};
-        float xnext = (lane < kTile && lane < L) ? (float)in[lane] : 0.0f; /* extractwav.cpp:55-58 */
+        const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
+        GtLo s = {};
+        InFeed feed;
+        feed.start(in, L, lane); /* extractwav.cpp:55-58 */
         for (long long j = 0; j < niter; ++j) {
-            if (j < ntile) {
-                if (lane < kTile) xs[lane] = xnext;
-                const long long nn = (j + 1) * kTile + lane;
-                if (lane < kTile) xnext = (nn < L) ? (float)in[nn] : 0.0f;
+            RS_T_BEGIN;
+            if (j < ntile && !(SEA_RS_SKIP & 1)) {
+                feed.tile(in, L, j, lane, xs);
                 wave_sync();
-                float2(*o)[64] = S.pq[j & 1];
+                v2f(*o)[64] = S.pq[j & 1];
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_lo(s, xs[t], f1, f2);
+                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_lo(s, xs[t], C);
                 wave_sync();
             }
+            RS_T_MID;
             tile_sync();
+            RS_T_END;
         }
+        RS_T_FLUSH(0);
     } else if (role == 1) {
-        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane], gain = a.tables->gain[lane];
-        GtHi s = {0, 0, 0, 0, 0, 0};
+        const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
+        const float gain = a.tables->gain[lane];
+        GtHi s = {};
         for (long long j = 0; j < niter; ++j) {
+            RS_T_BEGIN;
             const long long jt = j - 1;
-            if (jt >= 0 && jt < ntile) {
-                const float2(*i)[64] = S.pq[jt & 1];
+            if (jt >= 0 && jt < ntile && !(SEA_RS_SKIP & 2)) {
+                const v2f(*i)[64] = S.pq[jt & 1];
                 float(*o)[64] = S.g[jt & 1];
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_hi(s, i[t][lane], f1, f2, gain);
+                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_hi(s, i[t][lane], C, gain);
             }
+            RS_T_MID;
             tile_sync();
+            RS_T_END;
         }
+        RS_T_FLUSH(2);
     } else {
-        /* reverse[...] = gOut / midEar (extractwav.cpp:86-87), streamed to HBM in natural time order */
-        float *rin = a.inter + off * 64 + lane;
-        const float ear = a.tables->midEar[lane];
+        /* reverse[...] = gOut / midEar (extractwav.cpp:86-87), streamed to HBM tile by tile in the
+         * layout of inter_tile(): four fully contiguous 1 KB stores per tile.  The last tile is
+         * written whole; its steps past L carry the filter's response to the zero padding and are
+         * never consumed (the synthesis pass substitutes zeros there). */
+        float *dst = inter_base(a.inter, off, u) + lane * 4;
+        const DivConst ear = div_const(a.tables->midEar[lane]);
         for (long long j = 0; j < niter; ++j) {
+            RS_T_BEGIN;
             const long long jt = j - 2;
-            if (jt >= 0 && jt < ntile) {
-                const long long n0 = jt * kTile;
-                const int cnt = (L - n0 < kTile) ? (int)(L - n0) : kTile;
+            if (jt >= 0 && jt < ntile && !(SEA_RS_SKIP & 4)) {
                 const float(*g)[64] = S.g[jt & 1];
-                if (cnt == kTile) {
+                float *row = dst + jt * (kTile * 64);
+                float gv[kTile], v[kTile];
 #pragma unroll
-                    for (int t = 0; t < kTile; ++t) rin[(n0 + t) * 64] = g[t][lane] / ear;
-                } else {
-                    for (int t = 0; t < cnt; ++t) rin[(n0 + t) * 64] = g[t][lane] / ear;
-                }
+                for (int t = 0; t < kTile; ++t) gv[t] = g[t][lane];
+                div_tile16(gv, v, ear);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<float4 *>(row + k * 256) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
             }
+            RS_T_MID;
             tile_sync();
+            RS_T_END;
         }
+        RS_T_FLUSH(4);
     }
 }
 
@@ -180,94 +342,155 @@ __global__ __launch_bounds__(64) void gammatone_kernel(const float *in, float *o
                                                        const sea_gt_tables *t)
 {
     if (threadIdx.x != 0) return;
-    const float f1 = t->f1[chan], f2 = t->f2[chan], gain = t->gain[chan];
-    GtState s = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (long long n = 0; n < L; ++n) out[n] = gt_step(s, in[n], f1, f2, gain);
+    const GtCoef C = gt_coef(t->f1[chan], t->f2[chan]);
+    const float gain = t->gain[chan];
+    GtLo lo = {};
+    GtHi hi = {};
+    for (long long n = 0; n < L; ++n) {
+        const v2f pq1 = gt_step_lo(lo, in[n], C);
+        out[n] = gt_step_hi(hi, pq1, C, gain);
+    }
 }
 
-__global__ __launch_bounds__(192) void resynth_bwd_kernel(ResynthArgs a)
+/* Synthesis pass: FOUR waves per utterance.
+ *   R1  reads the stored tiles back to front (HBM), cascade stages 0-1
+ *   R2  cascade stages 2-3 -> filter output g into a padded tile
+ *   W   per step and channel: g / midEar, the mask-weighted raised-cosine overlap-add weight of that
+ *       sample (at most two overlapping frames), their product, written back IN PLACE
+ *   SUM lane = step: the 64 channel terms added in channel order (a 64-deep dependent chain, which
+ *       is why it has a wave of its own), (short) cast, store
+ * The g / product tile passes through three owners (R2, W, SUM), hence three buffers. */
+__global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
 {
-    __shared__ RsLds S;
-    __shared__ float prod[kTile * kTileStride];
+    __shared__ __attribute__((aligned(16))) v2f pq[2][kTile][64];          /* R1 -> R2 */
+    __shared__ __attribute__((aligned(16))) float gp[3][kTile * kTileStride]; /* R2 -> W -> SUM */
     __shared__ double olaUp[160], olaDown[160];
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long off = a.offsets[u], L = a.lengths[u];
     if (L < 320) return; /* no mask frame fits (wave-uniform exit before any barrier) */
-    const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 2;
-    for (int i = threadIdx.x; i < 160; i += 192) {
+    const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 3;
+    for (int i = threadIdx.x; i < 160; i += 256) {
         olaUp[i] = a.tables->olaUp[i];
         olaDown[i] = a.tables->olaDown[i];
     }
     tile_sync();
 
+    RS_T_DECL;
     if (role == 0) {
-        /* second pass over the time-reversed signal (extractwav.cpp:88), stages 0-1 */
-        const float *rin = a.inter + off * 64 + lane;
-        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane];
-        GtLo s = {0, 0, 0, 0};
-        constexpr int kAhead = 8;
-        float cur[kAhead], nxt[kAhead];
+        /* second pass over the time-reversed signal (extractwav.cpp:88), stages 0-1.  Tile tb of
+         * this pass is tile ntile-1-tb of the analysis pass read back to front; the steps of the
+         * first one that lie past L are zeros (leading zeros leave the all-zero state untouched).
+         * HBM latency: the kMacro tiles of the NEXT macro step are requested before the current
+         * ones are worked on, one 1 KB request per quarter tile, so a request has kMacro tile
+         * periods (~4000 cycles) to complete before it is waited for. */
+        const float *src = inter_base(a.inter, off, u) + lane * 4;
+        const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
+        GtLo s = {};
+        float4 cur[kMacro][4], nxt[kMacro][4];
+        auto request = [&](float4(&b)[kMacro][4], long long macro) {
 #pragma unroll
-        for (int k = 0; k < kAhead; ++k) cur[k] = (k < L) ? rin[(L - 1 - k) * 64] : 0.0f;
-        for (long long j = 0; j < niter; ++j) {
-            if (j < ntile) {
-                float2(*o)[64] = S.pq[j & 1];
+            for (int m = 0; m < kMacro; ++m) {
+                long long tf = ntile - 1 - (macro * kMacro + m);
+                tf = (tf > 0) ? tf : 0; /* past the end of the pass: harmless re-read of tile 0 */
+                const float *row = src + tf * (kTile * 64);
 #pragma unroll
-                for (int t0 = 0; t0 < kTile; t0 += kAhead) {
+                for (int k = 0; k < 4; ++k) b[m][k] = *reinterpret_cast<const float4 *>(row + k * 256);
+            }
+        };
+        request(cur, 0);
+        for (long long j0 = 0; j0 < niter; j0 += kMacro) {
+            request(nxt, j0 / kMacro + 1);
 #pragma unroll
-                    for (int k = 0; k < kAhead; ++k) { /* time runs backwards: row index decreases */
-                        const long long nn = j * kTile + t0 + kAhead + k;
-                        nxt[k] = (nn < L) ? rin[(L - 1 - nn) * 64] : 0.0f;
+            for (int m = 0; m < kMacro; ++m) {
+                const long long j = j0 + m;
+                if (j >= niter) break;
+                RS_T_BEGIN;
+                if (j < ntile && !(SEA_RS_SKIP & 1)) {
+                    v2f(*o)[64] = pq[j & 1];
+                    float x[kTile]; /* x[t]: step t of this pass = step 15-t of the stored tile */
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        x[15 - 4 * k] = cur[m][k].x;
+                        x[14 - 4 * k] = cur[m][k].y;
+                        x[13 - 4 * k] = cur[m][k].z;
+                        x[12 - 4 * k] = cur[m][k].w;
+                    }
+                    if (j == 0) {
+                        const long long mTop = ntile * kTile - 1; /* sample index of step 0 */
+#pragma unroll
+                        for (int t = 0; t < kTile; ++t) x[t] = (mTop - t < L) ? x[t] : 0.0f;
                     }
 #pragma unroll
-                    for (int k = 0; k < kAhead; ++k) o[t0 + k][lane] = gt_step_lo(s, cur[k], f1, f2);
-#pragma unroll
-                    for (int k = 0; k < kAhead; ++k) cur[k] = nxt[k];
+                    for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_lo(s, x[t], C);
                 }
+                RS_T_MID;
+                tile_sync();
+                RS_T_END;
             }
-            tile_sync();
-        }
-    } else if (role == 1) {
-        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane], gain = a.tables->gain[lane];
-        GtHi s = {0, 0, 0, 0, 0, 0};
-        for (long long j = 0; j < niter; ++j) {
-            const long long jt = j - 1;
-            if (jt >= 0 && jt < ntile) {
-                const float2(*i)[64] = S.pq[jt & 1];
-                float(*o)[64] = S.g[jt & 1];
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_hi(s, i[t][lane], f1, f2, gain);
-            }
-            tile_sync();
+            for (int m = 0; m < kMacro; ++m)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cur[m][k] = nxt[m][k];
         }
-    } else {
+        RS_T_FLUSH(6);
+    } else if (role == 1) {
+        const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
+        const float gain = a.tables->gain[lane];
+        GtHi s = {};
+        int buf = 0; /* (j-1) % 3 */
+        for (long long j = 0; j < niter; ++j) {
+            RS_T_BEGIN;
+            const long long jt = j - 1;
+            if (jt >= 0 && jt < ntile && !(SEA_RS_SKIP & 2)) {
+                const v2f(*i)[64] = pq[jt & 1];
+                float *o = gp[buf] + lane;
+#pragma unroll
+                for (int t = 0; t < kTile; ++t) o[t * kTileStride] = gt_step_hi(s, i[t][lane], C, gain);
+            }
+            if (jt >= 0) buf = (buf == 2) ? 0 : buf + 1;
+            RS_T_MID;
+            tile_sync();
+            RS_T_END;
+        }
+        RS_T_FLUSH(8);
+    } else if (role == 2) {
         const long long F = (L - 320) / 160 + 1;
         const float *mask = a.mask + a.mask_offsets[u] * 64 + lane;
-        int16_t *out = a.out + off;
-        const float ear = a.tables->midEar[lane];
+        const DivConst ear = div_const(a.tables->midEar[lane]);
         const bool binary = a.binary != 0;
         /* mask value of row h as the weight code sees it: the IBM variant turns > 0.5 into 1.0 and
-         * skips everything else (resyth_64sub_IBM/cpp/extractwav.cpp:97-99); skipped == 0 here */
-        auto mask_row = [&](long long h) -> float {
-            if (h < 0 || h >= F) return 0.0f;
-            const float v = mask[h * 64];
-            return binary ? ((v > 0.5f) ? 1.0f : 0.0f) : v;
+         * skips everything else (resyth_64sub_IBM/cpp/extractwav.cpp:97-99); skipped == 0 here.
+         * The load itself (mask_raw) is unconditional and one hop ahead of the interpretation
+         * (mask_val), so its latency is never waited for inside the tile loop. */
+        auto mask_raw = [&](long long h) -> float {
+            const long long hc = (h < 0) ? 0 : ((h >= F) ? F - 1 : h);
+            return mask[hc * 64];
         };
-        /* output sample m = L-1-n runs backwards through hops of 160: r = m % 160 counts down.
-         * mh / mh1: mask rows of hop h (falling half) and h+1 (rising half); mhPrev: row h-1,
-         * fetched one hop ahead so that its latency is never exposed. */
-        long long h = (L - 1) / 160;
-        int r = (int)((L - 1) - h * 160);
-        float mh = mask_row(h), mh1 = mask_row(h + 1), mhPrev = mask_row(h - 1);
+        auto mask_val = [&](float raw, long long h) -> float {
+            if (h < 0 || h >= F) return 0.0f;
+            return binary ? ((raw > 0.5f) ? 1.0f : 0.0f) : raw;
+        };
+        /* output sample m runs backwards from mTop = 16 ntile - 1 (the samples m >= L of the first
+         * tile are the zero padding: computed, never stored) through hops of 160: r = m % 160 counts
+         * down.  mh / mh1: mask rows of hop h (falling half) and h+1 (rising half); rawPrev: row h-1. */
+        const long long mTop = ntile * kTile - 1;
+        long long h = mTop / 160;
+        int r = (int)(mTop - h * 160);
+        float mh = mask_val(mask_raw(h), h), mh1 = mask_val(mask_raw(h + 1), h + 1);
+        float rawPrev = mask_raw(h - 1);
+        int buf = 0; /* (j-2) % 3 */
         for (long long j = 0; j < niter; ++j) {
+            RS_T_BEGIN;
             const long long jt = j - 2;
-            if (jt >= 0 && jt < ntile) {
-                const long long n0 = jt * kTile;
-                const int cnt = (L - n0 < kTile) ? (int)(L - n0) : kTile;
-                const float(*g)[64] = S.g[jt & 1];
-                if (cnt == kTile && r >= kTile - 1) {
+            if (jt >= 0 && jt < ntile && !(SEA_RS_SKIP & 4)) {
+                float *g = gp[buf] + lane;
+                float gv[kTile], v[kTile];
+#pragma unroll
+                for (int t = 0; t < kTile; ++t) gv[t] = g[t * kTileStride];
+                div_tile16(gv, v, ear); /* :89-90, the value landing on sample m */
+                if (r >= kTile - 1) {
                     /* whole tile inside one hop (9 tiles out of 10): branch-free, 16 independent
                      * steps for the scheduler.  float(double(0.0f) + x) == float(x), so the first
                      * accumulation needs no add. */
@@ -275,49 +498,72 @@ __global__ __launch_bounds__(192) void resynth_bwd_kernel(ResynthArgs a)
                     const bool useH = mh > 0.0f, useH1 = mh1 > 0.0f;
 #pragma unroll
                     for (int t = 0; t < kTile; ++t) {
-                        const float v = g[t][lane] / ear; /* :89-90, the value landing on sample m */
                         const float w1 = (float)(olaDown[r - t] * mhD);
                         float w = useH ? w1 : 0.0f;
                         const float w2 = (float)((double)w + olaUp[r - t] * mh1D);
                         w = useH1 ? w2 : w;
-                        prod[t * kTileStride + lane] = w * v; /* :108-112 term of this channel */
+                        g[t * kTileStride] = w * v[t]; /* :108-112 term of this channel */
                     }
                     r -= kTile;
                     if (r < 0) { /* step into hop h-1 */
                         r += 160;
                         h--;
                         mh1 = mh;
-                        mh = mhPrev;
-                        mhPrev = mask_row(h - 1);
+                        mh = mask_val(rawPrev, h);
+                        rawPrev = mask_raw(h - 1);
                     }
                 } else {
-                    for (int t = 0; t < cnt; ++t) {
-                        const float v = g[t][lane] / ear;
+#pragma unroll
+                    for (int t = 0; t < kTile; ++t) {
                         float w = 0.0f; /* :91-107: falling half of frame h, then rising half of h+1 */
                         if (mh > 0.0f) w = (float)((double)w + olaDown[r] * (double)mh);
                         if (mh1 > 0.0f) w = (float)((double)w + olaUp[r] * (double)mh1);
-                        prod[t * kTileStride + lane] = w * v;
-                        if (--r < 0) { /* step into hop h-1 */
+                        g[t * kTileStride] = w * v[t];
+                        if (--r < 0) { /* step into hop h-1: the next row was requested a hop ago */
                             r = 159;
                             h--;
                             mh1 = mh;
-                            mh = mhPrev;
-                            mhPrev = mask_row(h - 1);
+                            mh = mask_val(rawPrev, h);
+                            rawPrev = mask_raw(h - 1);
                         }
                     }
                 }
-                wave_sync();
-                if (lane < cnt) { /* channel sum in order 0..63 for sample t = lane, (short) cast :120-121 */
-                    float acc = 0.0f;
-                    const float *row = prod + lane * kTileStride;
-#pragma unroll 16
-                    for (int c = 0; c < 64; ++c) acc += row[c];
-                    out[L - 1 - (n0 + lane)] = (int16_t)cast_i16(acc);
-                }
-                wave_sync();
             }
+            if (jt >= 0) buf = (buf == 2) ? 0 : buf + 1;
+            RS_T_MID;
             tile_sync();
+            RS_T_END;
         }
+        RS_T_FLUSH(10);
+    } else {
+        int16_t *out = a.out + off;
+        const long long mTop = ntile * kTile - 1;
+        int buf = 0; /* (j-3) % 3 */
+        for (long long j = 0; j < niter; ++j) {
+            RS_T_BEGIN;
+            const long long jt = j - 3;
+            if (jt >= 0 && jt < ntile && !(SEA_RS_SKIP & 8)) {
+                if (lane < kTile) { /* channel sum in order 0..63 for step t = lane, (short) cast :120-121 */
+                    const long long m = mTop - jt * kTile - lane;
+                    const float4 *row = reinterpret_cast<const float4 *>(gp[buf] + lane * kTileStride);
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int c4 = 0; c4 < 16; ++c4) {
+                        const float4 p = row[c4];
+                        acc += p.x;
+                        acc += p.y;
+                        acc += p.z;
+                        acc += p.w;
+                    }
+                    if (m < L) out[m] = (int16_t)cast_i16(acc);
+                }
+            }
+            if (jt >= 0) buf = (buf == 2) ? 0 : buf + 1;
+            RS_T_MID;
+            tile_sync();
+            RS_T_END;
+        }
+        RS_T_FLUSH(12);
     }
 }
 
@@ -397,32 +643,32 @@ __global__ __launch_bounds__(320) void subband_kernel(SubbandArgs a)
     const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 4;
     if (role == 0) {
         const int16_t *in = a.in + off;
-        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane];
-        GtLo s = {0, 0, 0, 0};
-        float xnext = (lane < kTile && lane < L) ? (float)in[lane] : 0.0f;
+        const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
+        GtLo s = {};
+        InFeed feed;
+        feed.start(in, L, lane);
         for (long long j = 0; j < niter; ++j) {
             if (j < ntile) {
-                if (lane < kTile) xs[lane] = xnext;
-                const long long nn = (j + 1) * kTile + lane;
-                if (lane < kTile) xnext = (nn < L) ? (float)in[nn] : 0.0f;
+                feed.tile(in, L, j, lane, xs);
                 wave_sync();
-                float2(*o)[64] = S.pq[j & 1];
+                v2f(*o)[64] = S.pq[j & 1];
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_lo(s, xs[t], f1, f2);
+                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_lo(s, xs[t], C);
                 wave_sync();
             }
             tile_sync();
         }
     } else if (role == 1) {
-        const float f1 = a.tables->f1[lane], f2 = a.tables->f2[lane], gain = a.tables->gain[lane];
-        GtHi s = {0, 0, 0, 0, 0, 0};
+        const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
+        const float gain = a.tables->gain[lane];
+        GtHi s = {};
         for (long long j = 0; j < niter; ++j) {
             const long long jt = j - 1;
             if (jt >= 0 && jt < ntile) {
-                const float2(*i)[64] = S.pq[jt & 1];
+                const v2f(*i)[64] = S.pq[jt & 1];
                 float(*o)[64] = S.g[jt & 1];
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_hi(s, i[t][lane], f1, f2, gain);
+                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_hi(s, i[t][lane], C, gain);
             }
             tile_sync();
         }
@@ -477,4 +723,37 @@ __global__ __launch_bounds__(320) void subband_kernel(SubbandArgs a)
     }
 }
 
+/* sea_selftest_div: every float pattern a inside the fast-division domain, every channel's divisor:
+ * div_fast / div_fast2 against a / d.  mismatches[0] = count of differing results, [1] = patterns
+ * tested per channel (domain size), for the host to report. */
+__global__ __launch_bounds__(256) void selftest_div_kernel(const sea_gt_tables *t, unsigned long long *mismatches)
+{
+    unsigned long long bad = 0, tested = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (int ch = 0; ch < 64; ++ch) {
+        const float d = t->midEar[ch];
+        const DivConst c = div_const(d);
+        for (unsigned long long v = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; v < (1ull << 32); v += stride) {
+            const float a = __uint_as_float((unsigned)v);
+            if (!div_in_domain(a)) continue;
+            const float want = a / d;
+            const float got = div_fast(a, c);
+            const v2f got2 = div_fast2(v2f{a, -a}, c);
+            bad += (__float_as_uint(got) != __float_as_uint(want)) ? 1 : 0;
+            bad += (__float_as_uint(got2.x) != __float_as_uint(want)) ? 1 : 0;
+            bad += (__float_as_uint(got2.y) != __float_as_uint(-want)) ? 1 : 0;
+            if (ch == 0) tested++;
+        }
+    }
+    if (bad) atomicAdd(&mismatches[0], bad);
+    if (tested) atomicAdd(&mismatches[1], tested);
+}
+
 } // namespace sea
+
+#ifdef SEA_RS_TIMING
+extern "C" int sea_debug_rs_timing(unsigned long long *out16)
+{
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(sea::g_rs_timing), 16 * sizeof(unsigned long long));
+}
+#endif

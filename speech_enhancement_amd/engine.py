@@ -284,9 +284,14 @@ class MaskBatch:
         return cls(torch.from_numpy(host).to(device), torch.from_numpy(offs).to(device), offs, rows)
 
 
+def resynth_scratch_elems(batch):
+    """float32 elements of the HBM intermediate of resynth_batch (sea_resynth_scratch_bytes / 4)."""
+    return int(_lib.load().sea_resynth_scratch_bytes(int(batch.total), int(batch.n_utt))) // 4
+
+
 def resynth_batch(batch, masks, binary=False, out=None, scratch=None, use_order=True):
     """64-band gammatone resynthesis of every utterance of the batch (two launches on the current
-    stream).  ``scratch`` (float32, batch.total*64 elements) may be passed to reuse the HBM-resident
+    stream).  ``scratch`` (float32, resynth_scratch_elems(batch) elements) may be passed to reuse the HBM-resident
     analysis intermediate between calls."""
     torch = _torch()
     lib = _lib.load()
@@ -295,7 +300,7 @@ def resynth_batch(batch, masks, binary=False, out=None, scratch=None, use_order=
     if out is None:
         out = torch.zeros_like(batch.data)
     if scratch is None:
-        scratch = torch.empty(batch.total * 64, dtype=torch.float32, device=batch.data.device)
+        scratch = torch.empty(resynth_scratch_elems(batch), dtype=torch.float32, device=batch.data.device)
     rc = lib.sea_resynth64_batch(_dptr(batch.data), _dptr(out), _dptr(batch.offsets), _dptr(batch.lengths),
                                  _dptr(masks.data), _dptr(masks.row_offsets), _dptr(scratch),
                                  _dptr(batch.order) if use_order else None, batch.n_utt, int(bool(binary)),

@@ -54,7 +54,7 @@ def main():
     if what & {"resynth", "ibm"}:
         masks = sea.MaskBatch.from_arrays([corpus.synth_mask(u, int(L)) for u, L in enumerate(batch.host_lengths)], dev)
         hops = int(np.sum((np.asarray(batch.host_lengths) - 320) // 160 + 1))
-        scratch = torch.empty(batch.total * 64, dtype=torch.float32, device=dev)
+        scratch = torch.empty(sea.resynth_scratch_elems(batch), dtype=torch.float32, device=dev)
         out = torch.zeros_like(batch.data)
         for name, binary in (("resynth", False), ("ibm", True)):
             if name not in what:

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""tools/ns_timing.py -- per-role work / barrier-wait cycles per frame of ns_denoise_pipe_kernel
+(needs the -DSEA_NS_TIMING variant: SEA_MI355X_LIB=ablate/libsea_ns_timing.so).  Equal-length batch."""
+import ctypes, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    dev = torch.device("cuda", 0)
+    L = 48000
+    base = corpus.synth_utterance(3, L)
+    lib = ctypes.CDLL(sea.LIB_PATH)
+    for n in (256, 1024):
+        batch = sea.PackedBatch.from_arrays([base] * n, dev)
+        for _ in range(2):
+            sea.ns_denoise_batch(batch)
+        torch.cuda.synchronize()
+        t = (ctypes.c_ulonglong * 8)()
+        assert lib.sea_debug_ns_timing(t) == 0
+        fr = L // 80 + 4
+        print(json.dumps({"n_utt": n, **{nm: {"work_cyc_per_frame": round(t[2 * i] / fr), "wait_cyc_per_frame": round(t[2 * i + 1] / fr)}
+                                         for i, nm in enumerate(["F", "B0", "B1", "S"])}}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
