@@ -104,10 +104,13 @@ __device__ __forceinline__ v2f gt_rot(const GtCoef &c, v2f s) { return c.f11 * s
 struct GtLo {
     v2f s0, s1;
 };
-__device__ __forceinline__ v2f gt_step_lo(GtLo &s, float in, const GtCoef &c)
+/* in2 = (in, in): callers pass a .xx / .yy swizzle of the register PAIR the sample already sits in,
+ * which the packed multiply takes as an operand select -- a lone float would first have to be moved
+ * into the low half of an even-aligned pair. */
+__device__ __forceinline__ v2f gt_step_lo(GtLo &s, v2f in2, const GtCoef &c)
 {
     const v2f r0 = gt_rot(c, s.s0), r1 = gt_rot(c, s.s1);
-    s.s0 = v2f{in, in} * c.f12 + r0; /* p0 = in*f1 + x0, q0 = in*f2 + y0 */
+    s.s0 = in2 * c.f12 + r0; /* p0 = in*f1 + x0, q0 = in*f2 + y0 */
     s.s1 = s.s0 + r1;
     return s.s1;
 }
@@ -241,6 +244,26 @@ struct InFeed {
     }
 };
 
+/* Stages 2-3 cut once more for the analysis pass (its LDS has room for the extra hand-over):
+ * stage 2 alone returns A = (s2' + r1) + 2 r2, the reference's partial sum of p3/q3 in its own order;
+ * stage 3 finishes s3' = A + r3 and emits p3*gain. */
+struct GtMid {
+    v2f s1old, s2;
+};
+__device__ __forceinline__ v2f gt_step_mid(GtMid &s, v2f pq1, const GtCoef &c)
+{
+    const v2f r1 = gt_rot(c, s.s1old), r2 = gt_rot(c, s.s2);
+    s.s2 = pq1 + r1 + r2;
+    s.s1old = pq1;
+    return s.s2 + r1 + 2.0f * r2;
+}
+__device__ __forceinline__ float gt_step_top(v2f &s3, v2f A, const GtCoef &c, float gain)
+{
+    const float out = s3.x * gain;
+    s3 = A + gt_rot(c, s3);
+    return out;
+}
+
 /* HBM intermediate between the analysis and the synthesis pass: per utterance ntile = ceil(L/16)
  * tiles of 16 time steps x 64 channels, tile = 4 KB = four 1 KB quarters, quarter k holding steps
  * 4k..4k+3 of every channel as one float4 per lane (lane = channel).  Both passes move a tile with
@@ -259,9 +282,12 @@ struct __attribute__((aligned(16))) RsLds {
 
 } // namespace
 
+/* Analysis pass: three waves per utterance (R1 stages 0-1 | R2 stage 2 | R3 stage 3, division by the
+ * middle-ear gain, HBM store), 16-step tiles, one barrier per tile. */
 __global__ __launch_bounds__(192, 3) void resynth_fwd_kernel(ResynthArgs a)
 {
-    __shared__ RsLds S;
+    __shared__ __attribute__((aligned(16))) v2f pq[2][kTile][64]; /* R1 -> R2: new (p1,q1) */
+    __shared__ __attribute__((aligned(16))) v2f pa[2][kTile][64]; /* R2 -> R3: partial sums A */
     __shared__ __attribute__((aligned(16))) float xs[kTile];
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -280,9 +306,13 @@ __global__ __launch_bounds__(192, 3) void resynth_fwd_kernel(ResynthArgs a)
             if (j < ntile && !(SEA_RS_SKIP & 1)) {
                 feed.tile(in, L, j, lane, xs);
                 wave_sync();
-                v2f(*o)[64] = S.pq[j & 1];
+                v2f(*o)[64] = pq[j & 1];
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_lo(s, xs[t], C);
+                for (int t = 0; t < kTile; t += 2) {
+                    const v2f x2 = *reinterpret_cast<const v2f *>(&xs[t]);
+                    o[t][lane] = gt_step_lo(s, x2.xx, C);
+                    o[t + 1][lane] = gt_step_lo(s, x2.yy, C);
+                }
                 wave_sync();
             }
             RS_T_MID;
@@ -292,16 +322,15 @@ __global__ __launch_bounds__(192, 3) void resynth_fwd_kernel(ResynthArgs a)
         RS_T_FLUSH(0);
     } else if (role == 1) {
         const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
-        const float gain = a.tables->gain[lane];
-        GtHi s = {};
+        GtMid s = {};
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
             const long long jt = j - 1;
             if (jt >= 0 && jt < ntile && !(SEA_RS_SKIP & 2)) {
-                const v2f(*i)[64] = S.pq[jt & 1];
-                float(*o)[64] = S.g[jt & 1];
+                const v2f(*i)[64] = pq[jt & 1];
+                v2f(*o)[64] = pa[jt & 1];
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_hi(s, i[t][lane], C, gain);
+                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_mid(s, i[t][lane], C);
             }
             RS_T_MID;
             tile_sync();
@@ -309,21 +338,24 @@ __global__ __launch_bounds__(192, 3) void resynth_fwd_kernel(ResynthArgs a)
         }
         RS_T_FLUSH(2);
     } else {
-        /* reverse[...] = gOut / midEar (extractwav.cpp:86-87), streamed to HBM tile by tile in the
-         * layout of inter_tile(): four fully contiguous 1 KB stores per tile.  The last tile is
-         * written whole; its steps past L carry the filter's response to the zero padding and are
-         * never consumed (the synthesis pass substitutes zeros there). */
+        /* stage 3, then reverse[...] = gOut / midEar (extractwav.cpp:86-87), streamed to HBM tile by
+         * tile in the layout of inter_base(): four fully contiguous 1 KB stores per tile.  The last
+         * tile is written whole; its steps past L carry the filter's response to the zero padding
+         * and are never consumed (the synthesis pass substitutes zeros there). */
+        const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
+        const float gain = a.tables->gain[lane];
         float *dst = inter_base(a.inter, off, u) + lane * 4;
         const DivConst ear = div_const(a.tables->midEar[lane]);
+        v2f s3 = {0.0f, 0.0f};
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
             const long long jt = j - 2;
             if (jt >= 0 && jt < ntile && !(SEA_RS_SKIP & 4)) {
-                const float(*g)[64] = S.g[jt & 1];
+                const v2f(*i)[64] = pa[jt & 1];
                 float *row = dst + jt * (kTile * 64);
                 float gv[kTile], v[kTile];
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) gv[t] = g[t][lane];
+                for (int t = 0; t < kTile; ++t) gv[t] = gt_step_top(s3, i[t][lane], C, gain);
                 div_tile16(gv, v, ear);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -347,7 +379,7 @@ __global__ __launch_bounds__(64) void gammatone_kernel(const float *in, float *o
     GtLo lo = {};
     GtHi hi = {};
     for (long long n = 0; n < L; ++n) {
-        const v2f pq1 = gt_step_lo(lo, in[n], C);
+        const v2f pq1 = gt_step_lo(lo, v2f{in[n], in[n]}, C);
         out[n] = gt_step_hi(hi, pq1, C, gain);
     }
 }
@@ -400,6 +432,16 @@ __global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
             }
         };
         request(cur, 0);
+        { /* the steps of the very first tile that lie past L are the zero padding */
+            const long long top = (ntile - 1) * kTile; /* sample index of stored step 0 of that tile */
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cur[0][k].x = (top + 4 * k + 0 < L) ? cur[0][k].x : 0.0f;
+                cur[0][k].y = (top + 4 * k + 1 < L) ? cur[0][k].y : 0.0f;
+                cur[0][k].z = (top + 4 * k + 2 < L) ? cur[0][k].z : 0.0f;
+                cur[0][k].w = (top + 4 * k + 3 < L) ? cur[0][k].w : 0.0f;
+            }
+        }
         for (long long j0 = 0; j0 < niter; j0 += kMacro) {
             request(nxt, j0 / kMacro + 1);
 #pragma unroll
@@ -409,21 +451,16 @@ __global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
                 RS_T_BEGIN;
                 if (j < ntile && !(SEA_RS_SKIP & 1)) {
                     v2f(*o)[64] = pq[j & 1];
-                    float x[kTile]; /* x[t]: step t of this pass = step 15-t of the stored tile */
+                    /* step t of this pass = step 15-t of the stored tile: quarters 3..0, each w,z,y,x */
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        x[15 - 4 * k] = cur[m][k].x;
-                        x[14 - 4 * k] = cur[m][k].y;
-                        x[13 - 4 * k] = cur[m][k].z;
-                        x[12 - 4 * k] = cur[m][k].w;
+                    for (int k = 3; k >= 0; --k) {
+                        const v2f lo2 = {cur[m][k].x, cur[m][k].y}, hi2 = {cur[m][k].z, cur[m][k].w};
+                        const int t = 4 * (3 - k);
+                        o[t + 0][lane] = gt_step_lo(s, hi2.yy, C);
+                        o[t + 1][lane] = gt_step_lo(s, hi2.xx, C);
+                        o[t + 2][lane] = gt_step_lo(s, lo2.yy, C);
+                        o[t + 3][lane] = gt_step_lo(s, lo2.xx, C);
                     }
-                    if (j == 0) {
-                        const long long mTop = ntile * kTile - 1; /* sample index of step 0 */
-#pragma unroll
-                        for (int t = 0; t < kTile; ++t) x[t] = (mTop - t < L) ? x[t] : 0.0f;
-                    }
-#pragma unroll
-                    for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_lo(s, x[t], C);
                 }
                 RS_T_MID;
                 tile_sync();
@@ -653,7 +690,11 @@ __global__ __launch_bounds__(320) void subband_kernel(SubbandArgs a)
                 wave_sync();
                 v2f(*o)[64] = S.pq[j & 1];
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_lo(s, xs[t], C);
+                for (int t = 0; t < kTile; t += 2) {
+                    const v2f x2 = *reinterpret_cast<const v2f *>(&xs[t]);
+                    o[t][lane] = gt_step_lo(s, x2.xx, C);
+                    o[t + 1][lane] = gt_step_lo(s, x2.yy, C);
+                }
                 wave_sync();
             }
             tile_sync();

@@ -24,7 +24,7 @@ def main():
         t = (ctypes.c_ulonglong * 16)()
         assert lib.sea_debug_rs_timing(t) == 0
         tiles = L / 16
-        names = ["fwd R1", "fwd R2", "fwd H", "bwd R1", "bwd R2", "bwd W", "bwd SUM"]
+        names = ["fwd R1", "fwd R2", "fwd R3", "bwd R1", "bwd R2", "bwd W", "bwd SUM"]
         print(json.dumps({"n_utt": n, **{nm: {"work_cyc_per_tile": round(t[2 * i] / tiles), "wait_cyc_per_tile": round(t[2 * i + 1] / tiles)}
                                          for i, nm in enumerate(names)}}), flush=True)
 
