@@ -41,8 +41,6 @@ PROBE(k_sqrt_dep, asm volatile("v_sqrt_f32 %0, %0" : "+v"(a));, )
 PROBE(k_lds_rt, asm volatile("ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(a) : "v"(addr));, )
 PROBE(k_lds_wr_rd, asm volatile("ds_write_b32 %1, %0\n ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "+v"(a) : "v"(addr));, )
 PROBE(k_lds_b128_rt, asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(q) : "v"(addr4));, float4 q; unsigned addr4 = (threadIdx.x & 63) * 16)
-PROBE(k_salu_dep, asm volatile("s_add_u32 %0, %0, 1" : "+s"(si));, int si = 0)
-PROBE(k_valu_salu_mix, asm volatile("v_add_f32 %0, %0, %2\n s_add_u32 %1, %1, 1" : "+v"(a), "+s"(si) : "v"(e));, int si = 0)
 PROBE(k_readfirstlane, asm volatile("v_readfirstlane_b32 %1, %0\n v_add_f32 %0, %1, %0" : "+v"(a), "=s"(si));, int si = 0)
 PROBE(k_cndmask_dep, asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(e) : "vcc");, )
 PROBE(k_dpp_shr, asm volatile("s_nop 1\n v_add_f32_dpp %0, %0, %1 wave_shr:1" : "+v"(a) : "v"(e));, )
@@ -66,7 +64,7 @@ int main()
     RUN(k_pk_dep, 1); RUN(k_pk_2chains, 2); RUN(k_pkmul_dep, 1);
     RUN(k_f64_dep, 1); RUN(k_f64_2chains, 2); RUN(k_fma64_dep, 1); RUN(k_rcp_dep, 1); RUN(k_sqrt_dep, 1);
     RUN(k_lds_rt, 1); RUN(k_lds_wr_rd, 1); RUN(k_lds_b128_rt, 1);
-    RUN(k_salu_dep, 1); RUN(k_valu_salu_mix, 2); RUN(k_readfirstlane, 2); RUN(k_cndmask_dep, 2); RUN(k_dpp_shr, 1);
+    RUN(k_readfirstlane, 2); RUN(k_cndmask_dep, 2); RUN(k_dpp_shr, 1);
     RUN(k_barrier, 1);
     return 0;
 }
