@@ -105,13 +105,16 @@ def cpu_baseline(batch, n_sample, threads):
     def work(i):
         outs[i] = lib.etsi_denoise(utts[i])
 
+    passes = 3  # ~20 core-seconds of CPU work in total
     with quiet_stderr():
-        t0 = time.perf_counter()
         with ThreadPoolExecutor(max_workers=cores) as ex:
-            list(ex.map(work, range(len(utts))))
-        dt = time.perf_counter() - t0
-    return dict(value=frames / dt, unit="frames/s", cores=cores, kind=kind,
-                sample=f"first {len(utts)} utterances of the shard ({frames} frames, {dt:.2f} s wall)"), outs
+            t0 = time.perf_counter()
+            for _ in range(passes):
+                list(ex.map(work, range(len(utts))))
+            dt = time.perf_counter() - t0
+    return dict(value=passes * frames / dt, unit="frames/s", cores=cores, kind=kind,
+                sample=f"{passes} passes over the first {len(utts)} utterances of the shard "
+                       f"({passes * frames} frames, {dt:.2f} s wall on {cores} threads)"), outs
 
 
 def main():
