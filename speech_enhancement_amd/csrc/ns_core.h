@@ -608,6 +608,74 @@ __device__ __forceinline__ bool dc_filter(const float *dif, float *out, float &y
     return redo;
 }
 
+/* The three lane-redundant in-order chains of the helper wave, advanced TOGETHER: a wave64 issues a
+ * dependent vector instruction every 8 clk but independent ones every 4-5 (tools/lat_probe.hip), so
+ * interleaving the VAD sum (64 + sum sq[0..79]), the denSigSE1 sum (den[0..64]) and the DC-offset
+ * recurrence (dif[0..79] -> out[0..79], float FMA form of dc_filter) costs little more than the
+ * longest of them alone.  All three are always computed; the caller discards what it does not
+ * need (the arrays are always readable).  Ends with wave_sync(). */
+__device__ __forceinline__ void helper_chains(const float *sq, const float *den, const float *dif, float *out,
+                                              float &vadSum, float &denSum, float &y)
+{
+    float a = 64.0f, b = 0.0f;
+#pragma unroll 4
+    for (int n = 0; n < 64; n += 4) {
+        const float4 s4 = *reinterpret_cast<const float4 *>(&sq[n]);
+        const float4 e4 = *reinterpret_cast<const float4 *>(&den[n]);
+        const float4 d4 = *reinterpret_cast<const float4 *>(&dif[n]);
+        float4 o;
+        a += s4.x; b += e4.x; y = __fmaf_rn(0.9990234375f, y, d4.x); o.x = y;
+        a += s4.y; b += e4.y; y = __fmaf_rn(0.9990234375f, y, d4.y); o.y = y;
+        a += s4.z; b += e4.z; y = __fmaf_rn(0.9990234375f, y, d4.z); o.z = y;
+        a += s4.w; b += e4.w; y = __fmaf_rn(0.9990234375f, y, d4.w); o.w = y;
+        *reinterpret_cast<float4 *>(&out[n]) = o;
+    }
+    b += den[64];
+#pragma unroll
+    for (int n = 64; n < SEA_HOP; n += 4) {
+        const float4 s4 = *reinterpret_cast<const float4 *>(&sq[n]);
+        const float4 d4 = *reinterpret_cast<const float4 *>(&dif[n]);
+        float4 o;
+        a += s4.x; y = __fmaf_rn(0.9990234375f, y, d4.x); o.x = y;
+        a += s4.y; y = __fmaf_rn(0.9990234375f, y, d4.y); o.y = y;
+        a += s4.z; y = __fmaf_rn(0.9990234375f, y, d4.z); o.z = y;
+        a += s4.w; y = __fmaf_rn(0.9990234375f, y, d4.w); o.w = y;
+        *reinterpret_cast<float4 *>(&out[n]) = o;
+    }
+    vadSum = a;
+    denSum = b;
+    wave_sync();
+}
+
+/* second half of dc_filter(): the exactness guard of the float-FMA recurrence over one frame and,
+ * if it fails, the exact double recomputation.  y0 = state before the frame, y = after (updated). */
+__device__ __forceinline__ bool dc_verify(const float *dif, float *out, float y0, float &y, int lane)
+{
+    bool unsafe = false;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int n = lane + 64 * k;
+        if (n < SEA_HOP) {
+            const float ad = fabsf(dif[n]);
+            const float ay = fabsf(n == 0 ? y0 : out[n - 1]);
+            const bool ok = (ad == 0.0f) || (ay == 0.0f) ||
+                            (ay >= ad * 0x1p-16f && ay <= ad * 0x1p26f && ad < 0x1p100f && ad > 0x1p-100f);
+            unsafe |= !ok;
+        }
+    }
+    const bool redo = __ballot(unsafe) != 0ull;
+    if (redo) {
+        wave_sync();
+        y = y0;
+        for (int n = 0; n < SEA_HOP; ++n) {
+            y = (float)__fma_rn(0.9990234375, (double)y, (double)dif[n]);
+            out[n] = y;
+        }
+    }
+    wave_sync();
+    return redo;
+}
+
 /* DoNoiseSup (NoiseSup.c:1061-1440) for one 80-sample frame.  Lanes 0..39 pass samples 2l and
  * 2l+1.  Returns true when L.outb[0..79] holds a DC-filtered output frame. */
 __device__ __forceinline__ bool ns_tick(NsLds &L, NsRegs &s, const NsConst &C, int lane, float x0, float x1)

@@ -47,7 +47,7 @@ constexpr int kPipeWaves = 4;
 /* timing-only diagnostic (-DSEA_NS_TIMING): shader-clock cycles each role of workgroup 0 spends
  * working / waiting at the frame barrier -> g_ns_timing[role*2 + {0,1}] */
 #ifdef SEA_NS_TIMING
-__device__ unsigned long long g_ns_timing[8];
+__device__ unsigned long long g_ns_timing[16]; /* [8..15]: checkpoints inside S */
 struct RoleTimer {
     unsigned long long work = 0, wait = 0, t0 = 0, t1 = 0;
     __device__ __forceinline__ void begin() { t0 = clock64(); }
@@ -66,7 +66,15 @@ struct RoleTimer {
 #define NS_T_MID rt_.mid()
 #define NS_T_END rt_.end()
 #define NS_T_FLUSH(slot) rt_.flush(slot)
+#define NS_T_CK(k) do { const unsigned long long c_ = clock64(); ck_[k] += c_ - ckt_; ckt_ = c_; } while (0)
+#define NS_T_CK_DECL unsigned long long ck_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ckt_ = 0
+#define NS_T_CK_START ckt_ = clock64()
+#define NS_T_CK_FLUSH do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int q_ = 0; q_ < 8; ++q_) g_ns_timing[8 + q_] = ck_[q_]; } while (0)
 #else
+#define NS_T_CK(k)
+#define NS_T_CK_DECL
+#define NS_T_CK_START
+#define NS_T_CK_FLUSH
 #define NS_T_DECL
 #define NS_T_BEGIN
 #define NS_T_MID
@@ -295,50 +303,70 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
         float *outf = a.out_f32 ? a.out_f32 + off : nullptr;
         float dcX = 0.0f, dcY = 0.0f; /* prevSamples, NoiseSup.c:908-909 */
         int firstOut = -1;
+        NS_T_CK_DECL;
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
+            NS_T_CK_START;
             /* (1) VAD log-energy (NoiseSup.c:386-391) of the frame pushed at i-1 = tick tp; it is
-             *     the "current frame" buf[80..159] of tick tp+2 */
-            const long long fp = i - 1;
+             *     the "current frame" buf[80..159] of tick tp+2
+             * (2) in-order sum of denSigSE1 (NoiseSup.c:597-598) of the tick B0 finished at i-1
+             * (3) DC-offset filter (NoiseSup.c:182-198), int16 cast (ParmInterface.c:266), store of
+             *     the frame B1 finished at i-1.  etsi_denoise copies zeros until the first NoiseSup
+             *     output (AdvFrontEnd.c:186-190).
+             * The three serial chains are independent of each other and run interleaved. */
+            const long long fp = i - 1, fd = i - 2, fo = i - 4;
+            bool doVad = false, doDen = false, produced = false;
+            int tp = 0, td = 0;
+            const float *denSrc = L.r12[0].den;
             if (fp >= 0 && fp < nfr) {
                 const Rec01 &r = L.r01[fp & 1];
-                if ((SEA_ROLE_MASK & 16) && r.valid) {
-                    const int tp = r.tick;
-                    const float sum = vad_frame_sum(L.circ[0] + (tp & (kSlots - 1)) * kSlotLen, L.ssq, lane);
-                    const float en = vad_frame_energy(sum);
-                    if (lane == 0) L.frameEn[(tp + 2) & (kSlots - 1)] = en;
-                }
+                doVad = (SEA_ROLE_MASK & 16) && r.valid;
+                tp = r.tick;
             }
-            /* (2) in-order sum of denSigSE1 (NoiseSup.c:597-598) of the tick B0 finished at i-1 */
-            const long long fd = i - 2;
             if (fd >= 0 && fd < nfr) {
                 const Rec12 &r = L.r12[fd & 1];
-                if ((SEA_ROLE_MASK & 32) && r.valid && r.tick >= 3) {
-#ifdef SEA_ABLATE_GSUM
-                    const float total = r.den[0] + r.den[64];
-#else
-                    const float total = serial_sum<65>(r.den, 0.0f);
-#endif
-                    if (lane == 0) L.denSum[r.tick & (kSlots - 1)] = total;
+                doDen = (SEA_ROLE_MASK & 32) && r.valid && r.tick >= 3;
+                td = r.tick;
+                denSrc = r.den;
+            }
+            const bool haveOut = fo >= 0 && fo < nfr;
+            if (haveOut) produced = (SEA_ROLE_MASK & 64) && L.r34[fo & 1].produced != 0;
+            if (doVad) {
+                const float *frame = L.circ[0] + (tp & (kSlots - 1)) * kSlotLen;
+                const float x = frame[lane];
+                L.ssq[lane] = x * x;
+                if (lane < 16) {
+                    const float yv = frame[64 + lane];
+                    L.ssq[64 + lane] = yv * yv;
                 }
             }
-            /* (3) DC-offset filter (NoiseSup.c:182-198), int16 cast (ParmInterface.c:266), store of
-             *     the frame B1 finished at i-1.  etsi_denoise copies zeros until the first NoiseSup
-             *     output (AdvFrontEnd.c:186-190). */
-            const long long fo = i - 4;
-            if (fo >= 0 && fo < nfr) {
+            if (produced) {
                 const Rec34 &r = L.r34[fo & 1];
-                const bool produced = (SEA_ROLE_MASK & 64) && r.produced != 0;
+                const float xm1 = (lane == 0) ? dcX : r.out[lane - 1];
+                L.sdif[lane] = r.out[lane] - xm1;
+                if (lane < 16) L.sdif[64 + lane] = r.out[64 + lane] - r.out[63 + lane];
+                dcX = r.out[79];
+            }
+            NS_T_CK(0);
+            if (doVad || doDen || produced) {
+                wave_sync();
+                float vadSum, denTotal, y = dcY;
+                helper_chains(L.ssq, denSrc, L.sdif, L.sout, vadSum, denTotal, y);
+                NS_T_CK(1);
+                if (doVad) {
+                    const float en = vad_frame_energy(vadSum);
+                    if (lane == 0) L.frameEn[(tp + 2) & (kSlots - 1)] = en;
+                }
+                NS_T_CK(2);
+                if (doDen && lane == 0) L.denSum[td & (kSlots - 1)] = denTotal;
                 if (produced) {
-                    const float xm1 = (lane == 0) ? dcX : r.out[lane - 1];
-                    const float d0 = r.out[lane] - xm1;
-                    L.sdif[lane] = d0;
-                    if (lane < 16) L.sdif[64 + lane] = r.out[64 + lane] - r.out[63 + lane];
-                    dcX = r.out[79];
-                    wave_sync();
-                    dc_filter(L.sdif, L.sout, dcY, lane);
+                    dc_verify(L.sdif, L.sout, dcY, y, lane);
+                    dcY = y;
                     if (firstOut < 0) firstOut = (int)fo;
                 }
+                NS_T_CK(3);
+            }
+            if (haveOut) {
                 if (lane < 40) {
                     uint32_t packed = 0u;
                     if (produced) {
@@ -350,12 +378,14 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                 }
                 wave_sync();
             }
+            NS_T_CK(4);
             NS_T_MID;
             block_sync();
             NS_T_END;
         }
         if (a.first_out && lane == 0) a.first_out[u] = firstOut;
         NS_T_FLUSH(6);
+        NS_T_CK_FLUSH;
     }
 }
 
@@ -364,6 +394,6 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
 #ifdef SEA_NS_TIMING
 extern "C" int sea_debug_ns_timing(unsigned long long *out8)
 {
-    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(sea::g_ns_timing), 8 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(sea::g_ns_timing), 16 * sizeof(unsigned long long));
 }
 #endif

@@ -19,11 +19,12 @@ def main():
         for _ in range(2):
             sea.ns_denoise_batch(batch)
         torch.cuda.synchronize()
-        t = (ctypes.c_ulonglong * 8)()
+        t = (ctypes.c_ulonglong * 16)()
         assert lib.sea_debug_ns_timing(t) == 0
         fr = L // 80 + 4
         print(json.dumps({"n_utt": n, **{nm: {"work_cyc_per_frame": round(t[2 * i] / fr), "wait_cyc_per_frame": round(t[2 * i + 1] / fr)}
-                                         for i, nm in enumerate(["F", "B0", "B1", "S"])}}), flush=True)
+                                         for i, nm in enumerate(["F", "B0", "B1", "S"])},
+                          "S_checkpoints_cyc_per_frame(prep,chains,energy,verify,store)": [round(t[8 + q] / fr) for q in range(5)]}), flush=True)
 
 
 if __name__ == "__main__":
