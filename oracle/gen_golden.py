@@ -11,6 +11,9 @@ Files written (inputs and expected outputs only -- data, no reference source):
   tests/golden/ns_golden.npz        6 short utterances through etsi_denoise + the explicit
                                     NoiseSup/CompCeps driver: int16 out, float stream, cepstra,
                                     per-frame recursive state (scalars + 4 spectra)
+  tests/golden/afe_golden.npz       the same utterances through WaveProc -> CompCeps -> PostProc ->
+                                    VAD + flush: per-frame speech flags, features after CompCeps and
+                                    after PostProc, emitted feature frames with the VAD flag
   tests/golden/rfft_golden.npz      32 frames of 256 floats and their rfft
   tests/golden/compceps_golden.npz  16 stand-alone DoCompCeps frames (201 floats -> 14)
   tests/golden/tables_golden.npz    every constant table of NoiseSup and CompCeps
@@ -61,6 +64,17 @@ def main():
         pack[f"{name}/scal"] = tr["scal"]
         pack[f"{name}/spec"] = tr["spec"].astype(np.float32)
     np.savez_compressed(os.path.join(GOLD, "ns_golden.npz"), **pack)
+
+    # the chain the reference author commented out, driven by oracle/ref_driver.c
+    # through the reference's own DoWaveProc / DoCompCeps / DoPostProc / DoVADProc / FlushAdvProcess
+    afe = {}
+    for name, x in golden_utterances().items():
+        tr = ref.afe_trace(x)
+        afe[f"{name}/flags"] = tr["flags"]
+        afe[f"{name}/feat_cc"] = tr["feat_cc"]
+        afe[f"{name}/feat_pp"] = tr["feat_pp"]
+        afe[f"{name}/vad_out"] = tr["vad_out"]
+    np.savez_compressed(os.path.join(GOLD, "afe_golden.npz"), **afe)
 
     rng = np.random.default_rng(20251004)
     frames = (rng.standard_normal((32, 256)) * rng.uniform(0.01, 20000.0, (32, 1))).astype(np.float32)

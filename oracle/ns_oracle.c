@@ -318,6 +318,10 @@ typedef struct {
     int nbFrame[2];
     short flagVAD, hangOver, nbSpeechFrames;
     float meanEn;
+    /* VAD for frame dropping (struct vad_data_fd, NoiseSup.c:72-83; zeroed by DoNoiseSupInit :935-943) */
+    float fdMelMean, fdVarMean, fdAccTest, fdSpecMean, fdMelValues[2], fdSpecValues, fdSpeechInVADQ;
+    /* FEParamsX flags the frame-dropping VAD reads (ParmInterface.h:85-89) */
+    int speechFoundVar, speechFoundSpec, speechFoundMel, speechFoundVADNS, frameCounter;
 } ns_state;
 
 static void ns_init(ns_state *s)
@@ -457,6 +461,58 @@ static void ns_gain_fact(ns_state *s, int st, float *W)
     }
 }
 
+/* ---- VAD for frame dropping: measures taken inside the first stage (NoiseSup.c:672-839) --------
+ * Arithmetic follows the reference's promotions: float state, double literals (1.1, 1.5, 0.8 ...)
+ * promote the expression to double, the result is rounded to float on assignment; the frame
+ * counter is narrowed to int16 first (X_INT16 FrameCounter = nbFrame[0]). */
+#define FMAXF(a, b) (((a) > (b)) ? (a) : (b))
+
+static int speech_q_var(ns_state *s, const float *W)
+{ /* SpeechQVar, NoiseSup.c:798-839: variance of the first 64 Wiener gains */
+    const short ssize = 64, fc = (short)s->nbFrame[0];
+    float var = 0.0f, mean = 0.0f, specVar;
+    int i;
+    for (i = 0; i < ssize; i++) {
+        mean += W[i];
+        var += W[i] * W[i];
+    }
+    specVar = (var / ssize) - mean * mean / (ssize * ssize);
+    if (fc < 15) s->fdVarMean = FMAXF(s->fdVarMean, specVar);
+    if (specVar < s->fdVarMean * 1.5 && specVar > s->fdVarMean * 0.85)
+        s->fdVarMean = (s->fdVarMean * 0.8 + specVar * 0.2);
+    if (specVar <= s->fdVarMean * 0.25) s->fdVarMean = (s->fdVarMean * 0.97 + specVar * 0.03);
+    return (specVar > s->fdVarMean * 1.65) ? 1 : 0;
+}
+
+static int speech_q_spec(ns_state *s)
+{ /* SpeechQSpec, NoiseSup.c:686-727 */
+    const short fc = (short)s->nbFrame[0];
+    if (fc == 1) s->fdSpecMean = s->fdSpecValues;
+    if (fc < 15) {
+        float acceleration;
+        s->fdAccTest = 1.1 * (s->fdAccTest * (float)(fc - 1) + s->fdSpecValues) / (float)(fc);
+        acceleration = s->fdSpecValues / s->fdAccTest;
+        if (acceleration > 2.5) s->fdSpeechInVADQ = 1;
+        if (s->fdSpeechInVADQ == 0) s->fdSpecMean = FMAXF(s->fdSpecMean, s->fdSpecValues);
+    }
+    if (s->fdSpecValues < s->fdSpecMean * 1.5 && s->fdSpecValues > s->fdSpecMean * 0.75)
+        s->fdSpecMean = (s->fdSpecMean * 0.8 + s->fdSpecValues * 0.2);
+    if (s->fdSpecValues <= s->fdSpecMean * 0.5) s->fdSpecMean = (s->fdSpecMean * 0.97 + s->fdSpecValues * 0.03);
+    return (s->fdSpecValues > s->fdSpecMean * 1.65) ? 1 : 0;
+}
+
+static int speech_q_mel(ns_state *s)
+{ /* SpeechQMel, NoiseSup.c:744-781 */
+    const short fc = (short)s->nbFrame[0];
+    float smoothMel = 0.75 * s->fdMelValues[1] + 0.25 * s->fdMelValues[0];
+    s->fdMelValues[0] = s->fdMelValues[1];
+    if (fc < 15) s->fdMelMean = FMAXF(s->fdMelMean, smoothMel);
+    if (smoothMel < s->fdMelMean * 1.5 && smoothMel > s->fdMelMean * 0.75)
+        s->fdMelMean = (s->fdMelMean * 0.8 + smoothMel * 0.2);
+    if (smoothMel <= s->fdMelMean * 0.5) s->fdMelMean = (s->fdMelMean * 0.97 + smoothMel * 0.03);
+    return (smoothMel > s->fdMelMean * 3.25) ? 1 : 0;
+}
+
 /* One stage of the two-stage filter on buffer st; writes 80 filtered samples to dst. */
 static void ns_stage(ns_state *s, int st, float *dst)
 {
@@ -484,7 +540,16 @@ static void ns_stage(ns_state *s, int st, float *dst)
     }
     ns_vad(s, st, buf + HOP);
     ns_filter_calc(s, st, P, W);
+    if (st == 0) s->speechFoundVar = speech_q_var(s, W); /* NoiseSup.c:1255-1258 */
     mel_fb(W, T.mel, NMEL);
+    if (st == 0) { /* NoiseSup.c:1268-1281 */
+        float tempEn = 0.0f;
+        for (i = 0; i < NMEL; i++) tempEn += (float)W[i];
+        s->fdSpecValues = tempEn * tempEn - 3.0;
+        s->speechFoundSpec = speech_q_spec(s);
+        s->fdMelValues[1] = (float)(W[1] + W[2] + W[3]) / 3.0;
+        s->speechFoundMel = speech_q_mel(s);
+    }
     ns_gain_fact(s, st, W);
 
     /* DoMelIDCT (MelProc.c:357-378); only taps 0..8 are consumed (NoiseSup.c:660-669) */
@@ -513,10 +578,13 @@ static int ns_step(ns_state *s, const float *in, float *out)
     if (s->nIn1 - s->nIn2 > 2) {
         ns_stage(s, 0, s->buf[1] + 240);
         s->nIn2++;
+        s->speechFoundVADNS = (s->nbSpeechFrames > 4) ? 1 : 0; /* NoiseSup.c:1359-1365 */
+        s->frameCounter = s->nbFrame[0];                        /* :1366 */
     }
     if (s->nIn2 - s->nOut2 > 2) {
         ns_stage(s, 1, out);
         s->nOut2++;
+        s->frameCounter = s->nbFrame[0];
     }
     if (s->nIn1) memmove(s->buf[0], s->buf[0] + HOP, 240 * sizeof(float));
     if (s->nIn2) memmove(s->buf[1], s->buf[1] + HOP, 240 * sizeof(float));
@@ -659,6 +727,258 @@ long ora_ns_trace(const short *in, long n, short *out_i16, float *den_f32, float
         counts[0] = nout;
         counts[1] = nceps;
     }
+    return nfr;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * the chain after NoiseSup that the reference author commented out
+ * (ParmInterface.c:274-311): WaveProc -> CompCeps -> PostProc -> VAD, FlushAdvProcess at the end.
+ * ---------------------------------------------------------------------------------------- */
+
+/* DoWaveProc, WaveProc.c:397-455 with TeagerEng :216-226, GetTeagerFilter :244-330,
+ * GetMaximaPositions :102-190 (sort_it :60-84 yields ascending positions).  d[200] in place. */
+static void waveproc(float *d)
+{
+    enum { N = 200 };
+    float tw[N], energy = 0.0f, lowVal, highVal;
+    const float eps = (float)0.2; /* WP_EPS stored in an X_FLOAT32 field */
+    int q[N], sm[N], pos[24], R[12], Lf[12];
+    int i, j, k, p0 = 0, found = 0, cR = 0, cL = 0, nom, best = 0;
+
+    for (i = 0; i < N; i++) energy += (d[i] * d[i]);
+    if (!(energy >= 100.0)) return;
+
+    tw[0] = fabs(d[0] * d[0] - d[0] * d[1]);
+    for (i = 1; i < N - 1; i++) tw[i] = fabs(d[i] * d[i] - d[i - 1] * d[i + 1]);
+    tw[N - 1] = fabs(d[N - 1] * d[N - 1] - d[N - 2] * d[N - 1]);
+
+    /* 9-point running sum of (int)floor(0.25 T + 0.5) with the end values repeated; int32 wraps */
+    for (i = 0; i < N; i++) q[i] = (int)floor(tw[i] * 0.25 + 0.5);
+    for (i = 0; i < N; i++) {
+        unsigned acc = 0;
+        for (k = -4; k <= 4; k++) {
+            j = i + k;
+            j = j < 0 ? 0 : (j > N - 1 ? N - 1 : j);
+            acc += (unsigned)q[j];
+        }
+        sm[i] = (int)acc;
+    }
+
+    /* global maximum (first strict one), then neighbours 25..79 samples away, last of equals */
+    for (i = 0; i < N; i++)
+        if (sm[i] > best) {
+            best = sm[i];
+            p0 = i;
+            found = 1;
+        }
+    nom = 0;
+    if (found) {
+        R[0] = Lf[0] = p0;
+        while ((R[cR] + 25) < N && found) {
+            int m = 0;
+            found = 0;
+            for (i = 25; i < 80; i++)
+                if (R[cR] + i < N && sm[R[cR] + i] >= m) {
+                    found = 1;
+                    m = sm[R[cR] + i];
+                    R[cR + 1] = R[cR] + i;
+                }
+            if (found) cR++;
+        }
+        found = 1;
+        while ((Lf[cL] - 25) > 0 && found) {
+            int m = 0;
+            found = 0;
+            for (i = 25; i < 80; i++)
+                if (Lf[cL] - i > -1 && sm[Lf[cL] - i] >= m) {
+                    found = 1;
+                    m = sm[Lf[cL] - i];
+                    Lf[cL + 1] = Lf[cL] - i;
+                }
+            if (found) cL++;
+        }
+        for (i = cL; i >= 1; i--) pos[nom++] = Lf[i]; /* ascending: left ones, centre, right ones */
+        for (i = 0; i <= cR; i++) pos[nom++] = R[i];
+    }
+
+    lowVal = (1 - eps) / 2.0;
+    highVal = (1 + eps) / 2.0;
+    for (i = 0; i < N; i++) tw[i] = lowVal;
+    if (nom > 1) {
+        for (i = 0; i < nom - 1; i++)
+            for (j = pos[i] - 4; j < (pos[i] - 4) + ((80 * (pos[i + 1] - pos[i]) + 99) / 100); j++)
+                if (j >= 0) tw[j] = highVal;
+        for (j = pos[nom - 1] - 4; j < (pos[nom - 1] - 4) + ((80 * (pos[nom - 1] - pos[nom - 2]) + 99) / 100); j++)
+            if (j < N) tw[j] = highVal;
+    }
+    for (i = 0; i < N - 1; i++) d[i] *= (tw[i] + tw[i + 1]);
+    d[N - 1] *= (tw[N - 1] + tw[N - 1]);
+}
+
+/* DoPostProc (blind LMS equalisation of c1..c12), PostProc.c:123-149; w[12] is the state */
+static void postproc(float *coef14, float *w)
+{
+    static const float target[12] = {(float)-6.618909, (float)0.198269, (float)-0.740308, (float)0.055132,
+                                     (float)-0.227086, (float)0.144280, (float)-0.112451, (float)-0.146940,
+                                     (float)-0.327466, (float)0.134571, (float)0.027884,  (float)-0.114905};
+    const float lambda = (float)0.0087890625;
+    float wp = (coef14[13] * (float)64 - (float)211) / (float)64; /* Noc0 == 0: logE is Coef[13] */
+    int i;
+    if (wp < 0)
+        wp = 0;
+    else if (wp > 1)
+        wp = lambda;
+    else
+        wp *= lambda;
+    for (i = 0; i < 12; i++) {
+        float dif = ((coef14[i] - w[i]) - target[i]);
+        coef14[i] = coef14[i] - w[i];
+        w[i] += dif * wp;
+    }
+}
+
+/* DoVADProc / DoVADFlush, VAD.c:219-317 / :342-433 */
+typedef struct {
+    int focus, hangOver, hCount, vCount, flushFocus;
+    float buf[7][15];
+} vad_state;
+
+static void vad_init(vad_state *v)
+{
+    memset(v, 0, sizeof *v);
+    v->hangOver = 23;
+    v->flushFocus = -1;
+}
+
+static int vad_focal(int focus, int off)
+{
+    int t = focus + off;
+    if (t > 6) t -= 7;
+    if (t < 0) t += 7;
+    return t;
+}
+
+/* the decision shared by DoVADProc and DoVADFlush once FrameCounter > BUFFER_SIZE + 3 */
+static void vad_decide(vad_state *v, int focus, int frameCounter, float *feat15)
+{
+    int i, sum = 0, trigger = 0, r;
+    for (i = 0; i < 7; i++) {
+        r = vad_focal(focus, i + 1);
+        if (v->buf[r][14])
+            sum++;
+        else {
+            if (sum > trigger) trigger = sum;
+            sum = 0;
+        }
+    }
+    if (sum > trigger) trigger = sum;
+    if (trigger >= 4) {
+        v->hCount = v->hangOver;
+        if (frameCounter <= 35) v->hangOver = 50;
+    }
+    if (v->hCount && trigger < 3) v->hCount--;
+    if (trigger >= 3) v->vCount = 5;
+    if (v->vCount && trigger < 3) v->vCount--;
+    r = vad_focal(focus, 1);
+    for (i = 0; i < 15; i++) feat15[i] = v->buf[r][i];
+    feat15[14] = (v->vCount || v->hCount || trigger >= 3) ? 1.0f : 0.0f;
+}
+
+static int vad_proc(vad_state *v, float *feat15, const ns_state *s)
+{
+    int i, focus = v->focus + 1;
+    if (focus == 7) focus = 0;
+    for (i = 0; i < 14; i++) v->buf[focus][i] = feat15[i];
+    v->buf[focus][14] =
+        (s->speechFoundSpec || s->speechFoundMel || s->speechFoundVar || s->speechFoundVADNS) ? 1.0f : 0.0f;
+    v->focus = focus;
+    if (s->frameCounter > 7 + 3) {
+        vad_decide(v, focus, s->frameCounter, feat15);
+        return 1;
+    }
+    return 0;
+}
+
+static int vad_flush(vad_state *v, float *feat15, ns_state *s)
+{
+    int focus = v->focus;
+    if (v->flushFocus == -1) v->flushFocus = focus;
+    focus++;
+    if (focus == 7) focus = 0;
+    if (focus == v->flushFocus) return 0;
+    s->frameCounter++;
+    if (s->frameCounter > 7 + 3) vad_decide(v, focus, s->frameCounter, feat15);
+    v->focus = focus;
+    return 1; /* TRUE even when the counter gate kept FeatureBuffer untouched (VAD.c:421-428) */
+}
+
+/* Same contract as ref_afe_trace (oracle/ref_driver.c). */
+long ora_afe_trace(const short *in, long n, int *flags, float *feat_cc, float *feat_pp, float *vad_out,
+                   long *counts)
+{
+    ns_state *s = (ns_state *)malloc(sizeof *s);
+    vad_state vad;
+    float hist[241], lms[12], feat[15];
+    long nfr = n / HOP, f, nout = 0, nceps = 0, nvad = 0;
+    int onset = 0, i;
+
+    tables_init();
+    ns_init(s);
+    vad_init(&vad);
+    memset(hist, 0, sizeof hist);
+    memset(lms, 0, sizeof lms);
+    memset(feat, 0, sizeof feat);
+
+    for (f = 0; f < nfr; f++) {
+        float cur[HOP];
+        int any = 0;
+        memmove(hist, hist + HOP, (241 - HOP) * sizeof(float));
+        for (i = 0; i < HOP; i++) {
+            cur[i] = (float)in[f * HOP + i];
+            any |= (in[f * HOP + i] != 0);
+        }
+        if (any || onset) {
+            onset = 1;
+            if (ns_step(s, cur, hist + 241 - HOP)) {
+                nout++;
+                if (nout >= 3) {
+                    float frame[241];
+                    memcpy(frame, hist, sizeof frame);
+                    waveproc(frame + 1);
+                    compceps(frame + 1, feat);
+                    memcpy(feat_cc + nceps * 14, feat, 14 * sizeof(float));
+                    postproc(feat, lms);
+                    memcpy(feat_pp + nceps * 14, feat, 14 * sizeof(float));
+                    nceps++;
+                    if (vad_proc(&vad, feat, s)) {
+                        memcpy(vad_out + nvad * 15, feat, 15 * sizeof(float));
+                        nvad++;
+                    }
+                }
+            }
+        } else { /* null MFCC vector, ParmInterface.c:314-329 */
+            for (i = 0; i < 14; i++) feat[i] = 0.0f;
+            memcpy(vad_out + nvad * 15, feat, 14 * sizeof(float));
+            vad_out[nvad * 15 + 14] = 0.0f;
+            nvad++;
+        }
+        if (flags) {
+            int *p = flags + f * 5;
+            p[0] = s->speechFoundVar;
+            p[1] = s->speechFoundSpec;
+            p[2] = s->speechFoundMel;
+            p[3] = s->speechFoundVADNS;
+            p[4] = s->frameCounter;
+        }
+    }
+    while (vad_flush(&vad, feat, s)) {
+        memcpy(vad_out + nvad * 15, feat, 15 * sizeof(float));
+        nvad++;
+    }
+    free(s);
+    counts[0] = nout;
+    counts[1] = nceps;
+    counts[2] = nvad;
     return nfr;
 }
 

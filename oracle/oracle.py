@@ -76,6 +76,24 @@ class _Lib:
                     scal=None if scal is None else scal[:nfr],
                     spec=None if spec is None else spec[:nfr], nout=nout, nceps=nceps)
 
+    def afe_trace(self, x):
+        """The full per-frame chain: WaveProc -> CompCeps -> PostProc -> VAD + flush.
+        Returns dict(flags[nfr,5] = SpeechFoundVar/Spec/Mel/VADNS + FrameCounter, feat_cc[nceps,14],
+        feat_pp[nceps,14], vad_out[nvad,15] = emitted feature frames + VAD flag, nout, nceps, nvad)."""
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        nfr = x.size // 80
+        cap = max(nfr, 1) + 16
+        flags = np.zeros((max(nfr, 1), 5), np.int32)
+        fcc = np.zeros((cap, 14), np.float32)
+        fpp = np.zeros((cap, 14), np.float32)
+        vad = np.zeros((cap, 15), np.float32)
+        counts = np.zeros(3, np.int64)
+        self._f("afe_trace")(_ptr(x), ctypes.c_long(x.size), _ptr(flags), _ptr(fcc), _ptr(fpp), _ptr(vad),
+                             _ptr(counts))
+        nout, nceps, nvad = (int(c) for c in counts)
+        return dict(flags=flags[:nfr], feat_cc=fcc[:nceps], feat_pp=fpp[:nceps], vad_out=vad[:nvad],
+                    nout=nout, nceps=nceps, nvad=nvad)
+
     def compceps_frame(self, data201):
         d = np.ascontiguousarray(data201, dtype=np.float32)
         assert d.size == 201

@@ -16,6 +16,7 @@
  *                            records the float denoised stream, the per-frame NoiseSup state and
  *                            runs DoCompCeps exactly as the commented-out block
  *                            etsi/cpp/ParmInterface.c:275-293 would.
+ *   ref_afe_trace         -> the whole commented-out chain (WaveProc, CompCeps, PostProc, VAD, flush)
  */
 #include "NoiseSup.c" /* the reference TU itself: gives access to struct NoiseSupStructX */
 
@@ -103,6 +104,84 @@ long ref_ns_trace(const short *in, long n, short *out_i16, float *den_f32, float
     AdvProcessDelete(&fe);
     counts[0] = nout;
     counts[1] = nceps;
+    return nfr;
+}
+
+/*
+ * ref_afe_trace -- the per-frame chain the reference author commented out
+ * (etsi/cpp/ParmInterface.c:274-311): WaveProc -> CompCeps -> PostProc -> VAD on every NoiseSup
+ * output once the denoised buffer holds a frame, then FlushAdvProcess (ParmInterface.c:348-354) at
+ * the end of the input, exactly in that order, calling the reference's own functions through the
+ * slots AdvProcessAlloc wired (ParmInterface.c:58-82).  All-zero frames before the first non-zero
+ * one take the null-feature branch of DoAdvProcess itself (ParmInterface.c:314-329).
+ *
+ *   flags     5 ints per input frame after DoAdvProcess: SpeechFoundVar, SpeechFoundSpec,
+ *             SpeechFoundMel, SpeechFoundVADNS, FrameCounter
+ *   feat_cc   14 floats per cepstral frame after WaveProc + CompCeps
+ *   feat_pp   14 floats per cepstral frame after PostProc
+ *   vad_out   15 floats per EMITTED feature frame (14 features + the VAD flag), in emission order
+ *   counts    [0] NoiseSup outputs, [1] cepstral frames, [2] emitted feature frames
+ */
+long ref_afe_trace(const short *in, long n, int *flags, float *feat_cc, float *feat_pp, float *vad_out,
+                   long *counts)
+{
+    FEParamsX *fe = AdvProcessAlloc(8000);
+    short sig[80], den[80];
+    float feat[NUM_CEP_COEFF + 2];
+    float frameBuf[FRAME_BUF_SIZE + HP16k_MEL_USED];
+    long nfr = n / 80, f, nout = 0, nceps = 0, nvad = 0;
+    int i;
+
+    fe->Noc0 = 0;
+    AdvProcessInit(fe);
+    memset(den, 0, sizeof den);
+    memset(feat, 0, sizeof feat); /* DoVADFlush may return TRUE without writing it (VAD.c:421-428) */
+
+    for (f = 0; f < nfr; f++) {
+        NoiseSupStructX *NSX = fe->NSX;
+        long before = NSX->nsVar.buffers.nbFramesOutSecondStage;
+        long zeros_before = fe->ZeroFrameCounter;
+        for (i = 0; i < 80; i++) sig[i] = in[f * 80 + i];
+        DoAdvProcess(sig, den, feat, fe);
+        if (fe->ZeroFrameCounter > zeros_before) { /* null MFCC vector, VAD = NON_SPEECH, returned TRUE */
+            for (i = 0; i < 14; i++) vad_out[nvad * 15 + i] = feat[i];
+            vad_out[nvad * 15 + 14] = 0.0f;
+            nvad++;
+        }
+        if (NSX->nsVar.buffers.nbFramesOutSecondStage > before) {
+            nout++;
+            if (fe->offsetDenoisedFrame < 0) fe->offsetDenoisedFrame += fe->FrameShift;
+            if (fe->offsetDenoisedFrame >= 0) {
+                BufInGetLast(fe->denoisedBuf, frameBuf, fe->FrameLength + fe->offsetDenoisedFrame + 1);
+                fe->DoWaveProc(frameBuf + 1, fe);
+                fe->DoCompCeps(frameBuf + 1, feat, fe);
+                for (i = 0; i < 14; i++) feat_cc[nceps * 14 + i] = feat[i];
+                fe->DoPostProc(feat, fe);
+                for (i = 0; i < 14; i++) feat_pp[nceps * 14 + i] = feat[i];
+                nceps++;
+                if (fe->DoVADProc(feat, fe)) {
+                    for (i = 0; i < 15; i++) vad_out[nvad * 15 + i] = feat[i];
+                    nvad++;
+                }
+            }
+        }
+        if (flags) {
+            int *p = flags + f * 5;
+            p[0] = fe->SpeechFoundVar;
+            p[1] = fe->SpeechFoundSpec;
+            p[2] = fe->SpeechFoundMel;
+            p[3] = fe->SpeechFoundVADNS;
+            p[4] = fe->FrameCounter;
+        }
+    }
+    while (FlushAdvProcess(feat, fe)) {
+        for (i = 0; i < 15; i++) vad_out[nvad * 15 + i] = feat[i];
+        nvad++;
+    }
+    AdvProcessDelete(&fe);
+    counts[0] = nout;
+    counts[1] = nceps;
+    counts[2] = nvad;
     return nfr;
 }
 
