@@ -86,6 +86,26 @@ int sea_compceps_frames(const float *d_data201, float *d_coef14, long long nfram
 int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const long long *d_lengths,
                        const int *d_first_out, const long long *d_ceps_cum, long long total_frames,
                        float *d_ceps, int *d_n_ceps, int n_utt, void *stream);
+/* SURVEY 8(f) #3 -- the feature chain the reference keeps commented out (etsi/cpp/ParmInterface.c:274-311):
+ * WaveProc -> CompCeps -> PostProc -> VAD, then FlushAdvProcess (:348-354).
+ * Step 1: NoiseSup that also stores what the frame-dropping VAD votes over.  d_flags: one byte per
+ * output frame fo of utterance u at [d_offsets[u]/8 + 10*fo] (buffer of total_padded_samples/8
+ * bytes): bit 0 SpeechFoundVar, 1 SpeechFoundSpec, 2 SpeechFoundMel, 3 SpeechFoundVADNS
+ * (NoiseSup.c:1255-1281, :1359-1365).  d_onset[u]: index of the first non-zero frame. */
+int sea_ns_denoise_batch_fd(const short *d_in, short *d_out, float *d_out_f32,
+                            const long long *d_offsets, const long long *d_lengths, const int *d_order,
+                            int *d_first_out, unsigned char *d_flags, int *d_onset, int n_utt, void *stream);
+/* Step 2: features.  d_ceps_cum / d_feat_cum: n_utt+1 prefix sums of per-utterance capacities
+ * (>= lengths/80 - 6 cepstral frames, >= lengths/80 + 6 emitted frames).  d_feat_cc (and optionally
+ * d_feat_pp) receive 14 floats per cepstral frame after WaveProc+CompCeps (after PostProc);
+ * d_feat15 receives, per utterance and in emission order, the frames DoAdvProcess / FlushAdvProcess
+ * would hand to the recogniser: c1..c12, c0, logE and the VAD flag (null vectors for the all-zero
+ * lead, ParmInterface.c:314-329); d_n_feat[u] their number. */
+int sea_afe_features_batch(const float *d_den_f32, const unsigned char *d_flags, const long long *d_offsets,
+                           const long long *d_lengths, const int *d_first_out, const int *d_onset,
+                           const long long *d_ceps_cum, long long total_ceps, float *d_feat_cc, float *d_feat_pp,
+                           const long long *d_feat_cum, float *d_feat15, int *d_n_feat, int *d_n_ceps, int n_utt,
+                           void *stream);
 /* 64-band gammatone resynthesis over a batch.  mask rows (64 floats) of utterance u start at row
  * d_mask_offsets[u] and number (lengths[u]-320)/160+1.  d_inter is scratch of
  * sea_resynth_scratch_bytes(total padded samples of the batch, n_utt) bytes (the [time][64]

@@ -134,7 +134,7 @@ int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
     if (n_utt <= 0) return 0;
     DeviceCtx *c;
     if (ctx(&c)) return 1;
-    sea::NsBatchArgs a;
+    sea::NsBatchArgs a = {};
     a.in = d_in;
     a.out = d_out;
     a.out_f32 = d_out_f32;
@@ -154,6 +154,68 @@ int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
         hipLaunchKernelGGL(sea::ns_denoise_kernel, dim3(n_utt), dim3(64), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(sea::ns_denoise_pipe_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+int sea_ns_denoise_batch_fd(const short *d_in, short *d_out, float *d_out_f32,
+                            const long long *d_offsets, const long long *d_lengths, const int *d_order,
+                            int *d_first_out, unsigned char *d_flags, int *d_onset, int n_utt, void *stream)
+{
+    if (n_utt <= 0) return 0;
+    if (!d_out_f32 || !d_first_out || !d_flags || !d_onset)
+        return fail("ns_denoise_batch_fd: the float stream, first_out, flags and onset outputs are all required");
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    sea::NsBatchArgs a = {};
+    a.in = d_in;
+    a.out = d_out;
+    a.out_f32 = d_out_f32;
+    a.offsets = d_offsets;
+    a.lengths = d_lengths;
+    a.order = d_order;
+    a.first_out = d_first_out;
+    a.tables = c->ns;
+    a.n_utt = n_utt;
+    a.flags_out = d_flags;
+    a.onset_out = d_onset;
+    hipLaunchKernelGGL(sea::ns_denoise_pipe_fd_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sea_afe_features_batch(const float *d_den_f32, const unsigned char *d_flags, const long long *d_offsets,
+                           const long long *d_lengths, const int *d_first_out, const int *d_onset,
+                           const long long *d_ceps_cum, long long total_ceps, float *d_feat_cc, float *d_feat_pp,
+                           const long long *d_feat_cum, float *d_feat15, int *d_n_feat, int *d_n_ceps, int n_utt,
+                           void *stream)
+{
+    if (n_utt <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    sea::AfeArgs a = {};
+    a.den_f32 = d_den_f32;
+    a.flags = d_flags;
+    a.offsets = d_offsets;
+    a.lengths = d_lengths;
+    a.first_out = d_first_out;
+    a.onset = d_onset;
+    a.ceps_cum = d_ceps_cum;
+    a.feat_cc = d_feat_cc;
+    a.feat_pp = d_feat_pp;
+    a.feat_cum = d_feat_cum;
+    a.feat15 = d_feat15;
+    a.n_feat = d_n_feat;
+    a.n_ceps = d_n_ceps;
+    a.tables = c->cc;
+    a.n_utt = n_utt;
+    if (total_ceps > 0) {
+        const long long want = total_ceps < (1LL << 20) ? total_ceps : (1LL << 20);
+        hipLaunchKernelGGL(sea::afe_ceps_kernel, dim3((unsigned)want), dim3(64), 0, (hipStream_t)stream, a);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(sea::afe_vad_kernel, dim3(n_utt), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -185,4 +185,319 @@ __global__ __launch_bounds__(64) void compceps_kernel(CepsArgs a)
     }
 }
 
+/* ==================================================================================================
+ * the chain after NoiseSup that the reference has commented out
+ * (etsi/cpp/ParmInterface.c:274-311): WaveProc -> CompCeps -> PostProc -> VAD, FlushAdvProcess.
+ * WaveProc and CompCeps depend on the frame only -> one wave per cepstral frame (afe_ceps_kernel);
+ * PostProc (an LMS recurrence over frames) and the frame-dropping VAD (a 7-frame ring and two
+ * hangover counters) are serial per utterance and tiny -> one wave per utterance (afe_vad_kernel).
+ * ================================================================================================ */
+namespace {
+
+struct __attribute__((aligned(16))) WpLds {
+    float frame[204]; /* frame[0] = Data[-1], frame[1..200] = Data[0..199] */
+    float tw[200];
+    int q[200], sm[200];
+    int pos[24];
+};
+
+/* wave-wide arg-max of (value, index) pairs; ties go to the LOWER index if lowWins, else the higher.
+ * Entries with valid == false never win.  Returns the winning index, -1 if none is valid. */
+__device__ __forceinline__ int wave_argmax(int value, int index, bool valid, bool lowWins)
+{
+    int bv = value, bi = valid ? index : -1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const int ov = __shfl_xor(bv, off, 64), oi = __shfl_xor(bi, off, 64);
+        const bool take = (oi >= 0) && ((bi < 0) || (ov > bv) || (ov == bv && (lowWins ? (oi < bi) : (oi > bi))));
+        bv = take ? ov : bv;
+        bi = take ? oi : bi;
+    }
+    return bi;
+}
+
+/* DoWaveProc (WaveProc.c:397-455) on W.frame[1..200], in place: Teager energy (:216-226), its 9-point
+ * integer smoothing, maxima 25..79 samples apart (:102-190), a two-level window around them
+ * (:244-330).  Ends with wave_sync(). */
+__device__ __forceinline__ void waveproc_frame(WpLds &W, float *sq, int lane)
+{
+    constexpr int N = 200;
+    float *d = W.frame + 1;
+    /* low-energy check: in-order sum of squares (:423-427) */
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k;
+        if (i < N) sq[i] = d[i] * d[i];
+    }
+    wave_sync();
+    const float energy = serial_sum<200>(sq, 0.0f);
+    if (!((double)energy >= 100.0)) { /* wave-uniform */
+        wave_sync();
+        return;
+    }
+    /* Teager energy and its integer quarter, (int)floor(T * 0.25 + 0.5) in double */
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k;
+        if (i < N) {
+            const float a = d[i], l = d[i > 0 ? i - 1 : 0], r = d[i < N - 1 ? i + 1 : N - 1];
+            /* ends: |d0*d0 - d0*d1| and |dN-1*dN-1 - dN-2*dN-1| (the missing neighbour is the sample itself) */
+            const float t = (i == 0) ? fabsf(a * a - a * r) : ((i == N - 1) ? fabsf(a * a - l * a) : fabsf(a * a - l * r));
+            W.q[i] = (int)floor((double)t * 0.25 + 0.5);
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k;
+        if (i < N) {
+            unsigned acc = 0;
+#pragma unroll
+            for (int j = -4; j <= 4; ++j) {
+                int idx = i + j;
+                idx = idx < 0 ? 0 : (idx > N - 1 ? N - 1 : idx);
+                acc += (unsigned)W.q[idx];
+            }
+            W.sm[i] = (int)acc;
+        }
+    }
+    wave_sync();
+    /* global maximum: first index of the largest value, which must exceed 0 */
+    int nom = 0;
+    {
+        int bv = 0, bi = -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 64 * k;
+            if (i < N && W.sm[i] > bv) { /* ascending i per lane: strict > keeps the first */
+                bv = W.sm[i];
+                bi = i;
+            }
+        }
+        const int p0 = wave_argmax(bv, bi, bi >= 0, true);
+        if (p0 >= 0) {
+            int R[10], Lf[10], cR = 0, cL = 0;
+            R[0] = Lf[0] = p0;
+            bool found = true;
+#pragma unroll 1
+            while (R[cR] + 25 < N && found) { /* to the right: last of equals = the higher index */
+                const int idx = R[cR] + 25 + lane;
+                const bool in = lane < 55 && idx < N;
+                const int v = in ? W.sm[idx] : -1;
+                const int nx = wave_argmax(v, idx, in && v >= 0, false);
+                found = nx >= 0;
+                if (found) {
+#pragma unroll
+                    for (int c = 0; c < 9; ++c)
+                        if (c == cR) R[c + 1] = nx;
+                    cR++;
+                }
+            }
+            found = true;
+#pragma unroll 1
+            while (Lf[cL] - 25 > 0 && found) { /* to the left: last of equals in scan order = the lower index */
+                const int idx = Lf[cL] - 25 - lane;
+                const bool in = lane < 55 && idx > -1;
+                const int v = in ? W.sm[idx] : -1;
+                const int nx = wave_argmax(v, idx, in && v >= 0, true);
+                found = nx >= 0;
+                if (found) {
+#pragma unroll
+                    for (int c = 0; c < 9; ++c)
+                        if (c == cL) Lf[c + 1] = nx;
+                    cL++;
+                }
+            }
+            /* ascending: left ones (farthest first), centre, right ones */
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 9; c >= 1; --c)
+                    if (c <= cL) W.pos[nom++] = Lf[c];
+#pragma unroll
+                for (int c = 0; c < 10; ++c)
+                    if (c <= cR) W.pos[nom++] = R[c];
+            }
+            nom = cL + cR + 1;
+        }
+    }
+    wave_sync();
+    const float eps = (float)0.2;
+    const float lowVal = (float)((double)(1 - eps) / 2.0), highVal = (float)((double)(1 + eps) / 2.0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int j = lane + 64 * k;
+        if (j < N) {
+            bool high = false;
+            if (nom > 1) {
+                for (int i = 0; i < nom; ++i) {
+                    const int a = W.pos[i] - 4;
+                    const int gap = (i < nom - 1) ? (W.pos[i + 1] - W.pos[i]) : (W.pos[nom - 1] - W.pos[nom - 2]);
+                    high |= (j >= a) && (j < a + (80 * gap + 99) / 100);
+                }
+            }
+            W.tw[j] = high ? highVal : lowVal;
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k;
+        if (i < N) d[i] *= (W.tw[i] + W.tw[i < N - 1 ? i + 1 : N - 1]);
+    }
+    wave_sync();
+}
+
+} // namespace
+
+__global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
+{
+    __shared__ CcLds L;
+    __shared__ WpLds W;
+    const int lane = threadIdx.x;
+    CcConst C;
+    load_cc_const(C, a.tables, lane);
+    const long long total = a.ceps_cum[a.n_utt];
+    for (long long g = blockIdx.x; g < total; g += gridDim.x) {
+        int lo = 0, hi = a.n_utt; /* largest u with ceps_cum[u] <= g */
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.ceps_cum[mid] <= g) lo = mid; else hi = mid;
+        }
+        const int u = lo;
+        const long long j = g - a.ceps_cum[u];
+        const int f0 = a.first_out[u];
+        const long long nfr = a.lengths[u] / SEA_HOP;
+        const long long nout = (f0 >= 0) ? nfr - f0 : 0;
+        const long long nceps = (nout >= 3) ? nout - 2 : 0;
+        if (j == 0 && lane == 0 && a.n_ceps) a.n_ceps[u] = (int)nceps;
+        float *dst = a.feat_cc + g * SEA_CC_NCEP;
+        if (j < nceps) {
+            /* frameBuf of ParmInterface.c:281: Data[-1..199] = the last 241 denoised samples minus 40 */
+            const float *cur = a.den_f32 + a.offsets[u] + (f0 + j) * SEA_HOP;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = lane + 64 * k; /* frame[i] = Data[i-1] */
+                if (i <= SEA_WIN) W.frame[i] = (i == 0) ? ((j == 0) ? 0.0f : cur[-1]) : cur[i - 1];
+            }
+            wave_sync();
+            waveproc_frame(W, L.sq, lane);
+            compceps_frame(W.frame + 1, W.frame[0], dst, L, C, lane);
+        } else if (lane < SEA_CC_NCEP) {
+            dst[lane] = 0.0f;
+        }
+    }
+}
+
+/* DoPostProc (PostProc.c:123-149), DoVADProc (VAD.c:219-317), DoVADFlush (:342-433) and the null
+ * feature frames of the all-zero lead (ParmInterface.c:314-329), in emission order.  lane = feature
+ * index (0..13 cepstra/energies, 14 the VAD flag). */
+__global__ __launch_bounds__(64) void afe_vad_kernel(AfeArgs a)
+{
+    __shared__ float ring[7][16];
+    const int lane = threadIdx.x;
+    const int u = blockIdx.x;
+    const int f0 = a.first_out[u];
+    const long long nfr = a.lengths[u] / SEA_HOP;
+    const long long nout = (f0 >= 0) ? nfr - f0 : 0;
+    const long long nceps = (nout >= 3) ? nout - 2 : 0;
+    long long nnull = a.onset[u];
+    nnull = nnull < nfr ? nnull : nfr;
+    float *out = a.feat15 + a.feat_cum[u] * 15;
+    const float *cc = a.feat_cc + a.ceps_cum[u] * SEA_CC_NCEP;
+    float *pp = a.feat_pp ? a.feat_pp + a.ceps_cum[u] * SEA_CC_NCEP : nullptr;
+    const unsigned char *flg = a.flags + a.offsets[u] / 8;
+    long long nemit = 0;
+
+    for (long long k = 0; k < nnull; ++k) { /* null MFCC vectors, VAD = NON_SPEECH */
+        if (lane < 15) out[nemit * 15 + lane] = 0.0f;
+        nemit++;
+    }
+    if (lane < 16)
+#pragma unroll
+        for (int r = 0; r < 7; ++r) ring[r][lane] = 0.0f;
+    wave_sync();
+
+    static const float target[12] = {(float)-6.618909, (float)0.198269, (float)-0.740308, (float)0.055132,
+                                     (float)-0.227086, (float)0.144280, (float)-0.112451, (float)-0.146940,
+                                     (float)-0.327466, (float)0.134571, (float)0.027884,  (float)-0.114905};
+    const float tgt = (lane < 12) ? target[lane] : 0.0f;
+    const float lambda = (float)0.0087890625;
+    float wLMS = 0.0f;   /* weightLMS[lane] */
+    float feat = 0.0f;   /* FeatureBuffer[lane]: persists between calls like the reference's buffer */
+    int focus = 0, hangOver = 23, hCount = 0, vCount = 0, frameCounter = 0;
+
+    /* trigger = longest run of speech-flagged frames in the ring, scanned from focus+1 round to focus */
+    auto decide = [&](int fc) {
+        int sum = 0, trigger = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            int r = focus + i + 1;
+            r = r > 6 ? r - 7 : r;
+            if (ring[r][14] != 0.0f)
+                sum++;
+            else {
+                trigger = sum > trigger ? sum : trigger;
+                sum = 0;
+            }
+        }
+        trigger = sum > trigger ? sum : trigger;
+        if (trigger >= 4) {
+            hCount = hangOver;
+            if (fc <= 35) hangOver = 50;
+        }
+        if (hCount && trigger < 3) hCount--;
+        if (trigger >= 3) vCount = 5;
+        if (vCount && trigger < 3) vCount--;
+        int r = focus + 1;
+        r = r > 6 ? r - 7 : r;
+        feat = (lane < 15) ? ring[r][lane] : 0.0f;
+        if (lane == 14) feat = (vCount || hCount || trigger >= 3) ? 1.0f : 0.0f;
+    };
+
+    for (long long j = 0; j < nceps; ++j) {
+        /* PostProc on c1..c12; the weighting comes from logE = Coef[13] (Noc0 == 0) */
+        const float c = (lane < 14) ? cc[j * SEA_CC_NCEP + lane] : 0.0f;
+        const float logE = __shfl(c, 13, 64);
+        float wp = (logE * (float)64 - (float)211) / (float)64;
+        wp = (wp < 0) ? 0.0f : ((wp > 1) ? lambda : wp * lambda);
+        float v = c;
+        if (lane < 12) {
+            const float dif = ((c - wLMS) - tgt);
+            v = c - wLMS;
+            wLMS += dif * wp;
+        }
+        if (pp && lane < 14) pp[j * SEA_CC_NCEP + lane] = v;
+        if (lane < 14) feat = v;
+        /* DoVADProc */
+        frameCounter = (int)j + 5; /* nbFrame[0] when NoiseSup output j+3 appears */
+        focus = (focus + 1 == 7) ? 0 : focus + 1;
+        const int bits = flg[10 * (f0 + j + 2)];
+        if (lane < 14) ring[focus][lane] = feat;
+        if (lane == 14) ring[focus][14] = bits ? 1.0f : 0.0f;
+        wave_sync();
+        if (frameCounter > 10) {
+            decide(frameCounter);
+            if (lane < 15) out[nemit * 15 + lane] = feat;
+            nemit++;
+        }
+        wave_sync();
+    }
+    /* FlushAdvProcess until DoVADFlush returns FALSE */
+    {
+        const int flushFocus = focus;
+        for (;;) {
+            int nf = focus + 1;
+            nf = (nf == 7) ? 0 : nf;
+            if (nf == flushFocus) break;
+            focus = nf;
+            frameCounter++;
+            if (frameCounter > 10) decide(frameCounter);
+            if (lane < 15) out[nemit * 15 + lane] = feat;
+            nemit++;
+        }
+    }
+    if (lane == 0) a.n_feat[u] = (int)nemit;
+}
+
 } // namespace sea
+

@@ -280,6 +280,70 @@ __device__ __forceinline__ void gain_fact_update(NsRegs &s, float noiseEn)
     }
 }
 
+/* ---- VAD for frame dropping: the measures taken inside the first stage -----------
+ * SpeechQVar / SpeechQSpec / SpeechQMel (NoiseSup.c:672-839) and the VADNS flag (:1359-1365); their
+ * four bits per frame are what DoVADProc (VAD.c:219) votes over.  State is wave-uniform; every lane
+ * computes it.  Promotions follow the reference: float state, double literals, rounding to float on
+ * assignment; fc = the frame counter narrowed to int16. */
+struct NsFd {
+    float melMean, varMean, accTest, specMean, mel0, specValues, speechInVADQ;
+};
+__device__ __forceinline__ void fd_init(NsFd &d) { d.melMean = d.varMean = d.accTest = d.specMean = d.mel0 = d.specValues = d.speechInVADQ = 0.0f; }
+
+/* SpeechQVar: variance of the first 64 Wiener gains W (in LDS), two in-order float sums */
+__device__ __forceinline__ int fd_var(NsFd &d, const float *W, int fc)
+{
+    float mean = 0.0f, var = 0.0f;
+#pragma unroll 4
+    for (int i = 0; i < 64; i += 4) {
+        const float4 w = *reinterpret_cast<const float4 *>(&W[i]);
+        mean += w.x; var += w.x * w.x;
+        mean += w.y; var += w.y * w.y;
+        mean += w.z; var += w.z * w.z;
+        mean += w.w; var += w.w * w.w;
+    }
+    mean = uniform_f(mean);
+    var = uniform_f(var);
+    const float specVar = (var / 64.0f) - mean * mean / 4096.0f;
+    if (fc < 15) d.varMean = (d.varMean > specVar) ? d.varMean : specVar;
+    if ((double)specVar < (double)d.varMean * 1.5 && (double)specVar > (double)d.varMean * 0.85)
+        d.varMean = (float)((double)d.varMean * 0.8 + (double)specVar * 0.2);
+    if ((double)specVar <= (double)d.varMean * 0.25) d.varMean = (float)((double)d.varMean * 0.97 + (double)specVar * 0.03);
+    return ((double)specVar > (double)d.varMean * 1.65) ? 1 : 0;
+}
+
+/* SpeechQSpec + SpeechQMel on the 25 mel-filtered gains (in LDS); returns spec | mel << 1 */
+__device__ __forceinline__ int fd_spec_mel(NsFd &d, const float *mel, int fc)
+{
+    float tempEn = 0.0f;
+#pragma unroll
+    for (int i = 0; i < SEA_NMEL; ++i) tempEn += mel[i];
+    tempEn = uniform_f(tempEn);
+    d.specValues = (float)((double)(tempEn * tempEn) - 3.0);
+    if (fc == 1) d.specMean = d.specValues;
+    if (fc < 15) {
+        d.accTest = (float)(1.1 * (double)(d.accTest * (float)(fc - 1) + d.specValues) / (double)(float)fc);
+        const float acceleration = d.specValues / d.accTest;
+        if ((double)acceleration > 2.5) d.speechInVADQ = 1.0f;
+        if (d.speechInVADQ == 0.0f) d.specMean = (d.specMean > d.specValues) ? d.specMean : d.specValues;
+    }
+    if ((double)d.specValues < (double)d.specMean * 1.5 && (double)d.specValues > (double)d.specMean * 0.75)
+        d.specMean = (float)((double)d.specMean * 0.8 + (double)d.specValues * 0.2);
+    if ((double)d.specValues <= (double)d.specMean * 0.5)
+        d.specMean = (float)((double)d.specMean * 0.97 + (double)d.specValues * 0.03);
+    const int spec = ((double)d.specValues > (double)d.specMean * 1.65) ? 1 : 0;
+
+    const float mel1 = (float)((double)(float)(mel[1] + mel[2] + mel[3]) / 3.0);
+    const float smoothMel = (float)(0.75 * (double)mel1 + 0.25 * (double)d.mel0);
+    d.mel0 = mel1;
+    if (fc < 15) d.melMean = (d.melMean > smoothMel) ? d.melMean : smoothMel;
+    if ((double)smoothMel < (double)d.melMean * 1.5 && (double)smoothMel > (double)d.melMean * 0.75)
+        d.melMean = (float)((double)d.melMean * 0.8 + (double)smoothMel * 0.2);
+    if ((double)smoothMel <= (double)d.melMean * 0.5) d.melMean = (float)((double)d.melMean * 0.97 + (double)smoothMel * 0.03);
+    const int melf = ((double)smoothMel > (double)d.melMean * 3.25) ? 1 : 0;
+    return spec | (melf << 1);
+}
+
 /* FRONT half of a stage: analysis window on buf[60..259] (buf = 320-sample stage buffer, zero
  * padded to 256: NoiseSup.c:218-231), 256-point rfft, FFTtoPSD (129 power bins averaged pairwise to
  * 65: NoiseSup.c:249-270).  Depends on the buffer only -- no recursive state -- which is what lets
@@ -423,10 +487,11 @@ __device__ __forceinline__ void ns_idct_fir(float melOut, BackLds &B, const NsCo
  *   ST 0: the VAD frame log-energy arrives in frameEnExt; the 65 denSigSE1 values go to spectOut
  *         (summed later by the helper), the denEn registers are not touched.
  *   ST 1: the caller has loaded s.denEn0..2. */
-template <int ST, bool PIPE>
+template <int ST, bool PIPE, bool FD = false>
 __device__ __forceinline__ void ns_back(const float *psd, const float *buf, BackLds &B, NsRegs &s,
                                         const NsConst &C, float *dst, int lane, float frameEnExt = 0.0f,
-                                        float *spectOut = nullptr, const float *idctLds = nullptr)
+                                        float *spectOut = nullptr, const float *idctLds = nullptr,
+                                        NsFd *fd = nullptr, int *fdFlags = nullptr)
 {
     const float nSigLo = psd[lane], nSigHi = psd[64];
 
@@ -466,7 +531,19 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     }
     wave_sync();
 
+    int fdBits = 0;
+    if (FD && ST == 0) fdBits = fd_var(*fd, B.wbuf, nb16); /* NoiseSup.c:1255-1258, before DoMelFB */
+
     float melOut = ns_mel_fb(B, C, lane);
+
+    if (FD && ST == 0) { /* NoiseSup.c:1268-1281, on the mel-filtered gains; VADNS :1359-1365 */
+        if (lane < SEA_NMEL) B.mel[lane] = melOut;
+        wave_sync();
+        fdBits |= fd_spec_mel(*fd, B.mel, nb16) << 1;
+        fdBits |= (s.nbSpeech > 4) ? 8 : 0;
+        *fdFlags = fdBits; /* bit 0 Var, 1 Spec, 2 Mel, 3 VADNS */
+        wave_sync();
+    }
 
     /* --- DoGainFact (NoiseSup.c:581-642) --- */
     if (!(PIPE && ST == 0)) {

@@ -96,7 +96,7 @@ struct __attribute__((aligned(16))) Rec23 { /* F -> B1 */
 };
 struct __attribute__((aligned(16))) Rec34 { /* B1 -> S */
     float out[80]; /* second-stage filter output before the DC-offset filter */
-    int produced, pad0, pad1, pad2;
+    int produced, tick, pad1, pad2;
 };
 
 struct __attribute__((aligned(16))) PipeLds {
@@ -106,6 +106,7 @@ struct __attribute__((aligned(16))) PipeLds {
     float ssq[80], sdif[80], sout[80]; /* scratch of S */
     float frameEn[kSlots];          /* VAD log-energy for tick t at [t & 7] */
     float denSum[kSlots];           /* sum of denSigSE1 of tick t at [t & 7] */
+    int fdFlags[kSlots];            /* speech flags of tick t at [t & 7] (frame-dropping VAD variant) */
     float idctT[SEA_NMEL * 16];     /* mel-IDCT basis rows 0..8: [f][16], shared by B0 and B1 */
     Rec01 r01[2];
     Rec12 r12[2];
@@ -151,7 +152,8 @@ __device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables 
 
 } // namespace
 
-__global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
+template <bool FD>
+__device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
 {
     __shared__ PipeLds L;
     const int lane = threadIdx.x & 63;
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
         const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in + off);
         uint32_t nextw = (lane < 40 && nfr > 0) ? in32[lane] : 0u;
         int tick = 0; /* frames seen since (and including) the first non-zero one */
+        int onset = (int)nfr;
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
             /* stage 0, frame i */
@@ -199,6 +202,7 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                 int valid = 0;
                 if (any || tick > 0) {
                     valid = 1;
+                    if (FD && tick == 0) onset = (int)i;
                     tick++;
                     const float x0 = (float)(short)(w & 0xFFFFu), x1 = (float)(short)(w >> 16);
                     if (lane < 40) slot_store(L.circ[0], tick, lane, x0, x1);
@@ -234,6 +238,7 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
             block_sync();
             NS_T_END;
         }
+        if (FD && a.onset_out && lane == 0) a.onset_out[u] = onset;
         NS_T_FLUSH(0);
     } else if (role == 1) {
         /* ---- B0: BACK of stage 0; its 80 outputs enter the stage-1 buffer ---- */
@@ -241,6 +246,8 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
         load_back_const(C, a.tables, lane);
         NsRegs s;
         regs_init(s, C.eps);
+        NsFd fd;
+        fd_init(fd);
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
             const long long f = i - 1;
@@ -250,8 +257,10 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                 const int valid = r.valid, t = r.tick;
                 if ((SEA_ROLE_MASK & 2) && valid && t >= 3) {
                     float *tmp = L.back[0].sq; /* FIR output staged here, then stored with its mirror */
-                    ns_back<0, true>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
-                                     L.frameEn[t & (kSlots - 1)], o.den, L.idctT);
+                    int bits = 0;
+                    ns_back<0, true, FD>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
+                                         L.frameEn[t & (kSlots - 1)], o.den, L.idctT, &fd, &bits);
+                    if (FD && lane == 0) L.fdFlags[t & (kSlots - 1)] = bits;
                     if (lane < 40) {
                         const float2 v = *reinterpret_cast<const float2 *>(tmp + 2 * lane);
                         slot_store(L.circ[1], t, lane, v.x, v.y);
@@ -290,7 +299,10 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                                      L.idctT);
                     produced = 1;
                 }
-                if (lane == 0) o.produced = produced;
+                if (lane == 0) {
+                    o.produced = produced;
+                    o.tick = t;
+                }
             }
             NS_T_MID;
             block_sync();
@@ -376,6 +388,8 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
                     }
                     out32[fo * 40 + lane] = packed;
                 }
+                if (FD && produced && lane == 0 && a.flags_out)
+                    a.flags_out[off / 8 + 10 * fo] = (unsigned char)L.fdFlags[L.r34[fo & 1].tick & (kSlots - 1)];
                 wave_sync();
             }
             NS_T_CK(4);
@@ -388,6 +402,12 @@ __global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a)
         NS_T_CK_FLUSH;
     }
 }
+
+__global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a) { ns_pipe_body<false>(a); }
+
+/* the same pipeline with the first stage's speech measures (SpeechQVar/Spec/Mel, VADNS) evaluated in
+ * B0 and their four bits stored per output frame: input of the frame-dropping VAD */
+__global__ __launch_bounds__(256, 4) void ns_denoise_pipe_fd_kernel(NsBatchArgs a) { ns_pipe_body<true>(a); }
 
 } // namespace sea
 

@@ -21,6 +21,10 @@ struct NsBatchArgs {
     int *first_out;            /* optional: per utterance, frame index of the first NS output (-1: none) */
     const sea_ns_tables *tables;
     int n_utt;
+    /* frame-dropping VAD inputs (ns_denoise_pipe_fd_kernel only): */
+    unsigned char *flags_out;  /* per output frame fo of utterance u, at [offsets[u]/8 + 10*fo]: bit 0 SpeechFoundVar,
+                                * 1 Spec, 2 Mel, 3 VADNS of the tick that produced the frame */
+    int *onset_out;            /* per utterance: index of the first non-zero frame (number of frames if none) */
 };
 
 /* B independent streams, nframes frames of 80 floats each, state blobs of kNsStateFloats floats */
@@ -43,6 +47,25 @@ struct CepsArgs {
     const long long *ceps_cum; /* n_utt+1 prefix sums of the per-utterance frame capacity */
     float *ceps;               /* [ceps_cum[n_utt]][14] */
     int *n_ceps;               /* optional: valid cepstral frames per utterance */
+    const sea_cc_tables *tables;
+    int n_utt;
+};
+
+/* WaveProc -> CompCeps -> PostProc -> VAD (+ flush) on the float NoiseSup stream */
+struct AfeArgs {
+    const float *den_f32;          /* float NoiseSup stream (ns_denoise_pipe_fd_kernel) */
+    const unsigned char *flags;    /* its speech flags, [offsets[u]/8 + 10*fo] */
+    const long long *offsets;
+    const long long *lengths;
+    const int *first_out;          /* frame index of the first NoiseSup output, -1: none */
+    const int *onset;              /* index of the first non-zero frame */
+    const long long *ceps_cum;     /* n_utt+1 prefix sums of cepstral-frame capacities (>= lengths/80 - 6) */
+    float *feat_cc;                /* [ceps_cum[n_utt]][14]: after WaveProc + CompCeps */
+    float *feat_pp;                /* optional, same shape: after PostProc */
+    const long long *feat_cum;     /* n_utt+1 prefix sums of emitted-frame capacities (>= lengths/80 + 6) */
+    float *feat15;                 /* [feat_cum[n_utt]][15]: emitted feature frames + VAD flag */
+    int *n_feat;                   /* emitted frames per utterance */
+    int *n_ceps;                   /* optional */
     const sea_cc_tables *tables;
     int n_utt;
 };
@@ -76,6 +99,7 @@ struct SubbandArgs {
 __global__ void subband_kernel(SubbandArgs a);
 __global__ void ns_denoise_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_kernel(NsBatchArgs a);
+__global__ void ns_denoise_pipe_fd_kernel(NsBatchArgs a); /* + speech flags for the frame-dropping VAD */
 __global__ void ns_stream_kernel(NsStreamArgs a);
 __global__ void selftest_pi4_kernel(unsigned long long *mismatches);
 __global__ void selftest_dc_kernel(const float *dif, const float *y0, float *out, int *fellback, int ncases);
@@ -83,6 +107,8 @@ __global__ void selftest_log_kernel(const float *x, double *out, int n);
 __global__ void selftest_div_kernel(const sea_gt_tables *t, unsigned long long *mismatches);
 __global__ void rfft256_kernel(const float *in, float *out, long long nframes, const sea_fft_tables *t);
 __global__ void compceps_kernel(CepsArgs a);
+__global__ void afe_ceps_kernel(AfeArgs a); /* WaveProc + CompCeps, one wave per cepstral frame */
+__global__ void afe_vad_kernel(AfeArgs a);  /* PostProc + frame-dropping VAD + flush, one wave per utterance */
 __global__ void compceps_frames_kernel(const float *data201, float *coef14, long long nframes,
                                        const sea_cc_tables *t);
 __global__ void resynth_fwd_kernel(ResynthArgs a);

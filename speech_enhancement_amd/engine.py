@@ -261,6 +261,53 @@ def compceps_batch(batch, den_f32, first_out):
     return ceps, cum, n_ceps
 
 
+def afe_features_batch(batch, want_intermediates=False):
+    """The full ETSI AFE feature chain of the reference's DoAdvProcess as it was before the author
+    commented it out (etsi/cpp/ParmInterface.c:274-311): NoiseSup -> WaveProc -> CompCeps ->
+    PostProc -> frame-dropping VAD, with FlushAdvProcess at the end.
+
+    Returns a dict: feats (list of float32 [n_u,15] host arrays: c1..c12, c0, logE, VAD flag per
+    emitted frame), out (int16 denoised audio tensor, as ns_denoise_batch), and with
+    want_intermediates also flags (per output frame speech bits), feat_cc / feat_pp (per cepstral
+    frame, after CompCeps / PostProc), ceps_cum, n_ceps, first_out, onset."""
+    torch = _torch()
+    lib = _lib.load()
+    dev = batch.data.device
+    n = batch.n_utt
+    out = torch.zeros_like(batch.data)
+    f32 = torch.zeros(batch.total, dtype=torch.float32, device=dev)
+    first = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    onset = torch.zeros(n, dtype=torch.int32, device=dev)
+    flags = torch.zeros(max(batch.total // 8, 1), dtype=torch.uint8, device=dev)
+    _lib.check(lib.sea_ns_denoise_batch_fd(_dptr(batch.data), _dptr(out), _dptr(f32), _dptr(batch.offsets),
+                                           _dptr(batch.lengths), _dptr(batch.order), _dptr(first), _dptr(flags),
+                                           _dptr(onset), n, _stream_ptr()), "sea_ns_denoise_batch_fd")
+    nfr = np.asarray(batch.host_lengths) // 80
+    ccap = np.maximum(nfr - 6, 0).astype(np.int64)
+    ccum = np.concatenate(([0], np.cumsum(ccap))).astype(np.int64)
+    fcap = (nfr + 6).astype(np.int64)
+    fcum = np.concatenate(([0], np.cumsum(fcap))).astype(np.int64)
+    tc, tf = int(ccum[-1]), int(fcum[-1])
+    feat_cc = torch.zeros((max(tc, 1), 14), dtype=torch.float32, device=dev)
+    feat_pp = torch.zeros((max(tc, 1), 14), dtype=torch.float32, device=dev) if want_intermediates else None
+    feat15 = torch.zeros((max(tf, 1), 15), dtype=torch.float32, device=dev)
+    n_feat = torch.zeros(n, dtype=torch.int32, device=dev)
+    n_ceps = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_ccum, d_fcum = torch.from_numpy(ccum).to(dev), torch.from_numpy(fcum).to(dev)
+    _lib.check(lib.sea_afe_features_batch(_dptr(f32), _dptr(flags), _dptr(batch.offsets), _dptr(batch.lengths),
+                                          _dptr(first), _dptr(onset), _dptr(d_ccum), tc, _dptr(feat_cc),
+                                          _dptr(feat_pp) if feat_pp is not None else None, _dptr(d_fcum),
+                                          _dptr(feat15), _dptr(n_feat), _dptr(n_ceps), n, _stream_ptr()),
+               "sea_afe_features_batch")
+    torch.cuda.synchronize()
+    host15, nf = feat15.cpu().numpy(), n_feat.cpu().numpy()
+    res = dict(feats=[host15[fcum[u]:fcum[u] + int(nf[u])] for u in range(n)], out=out)
+    if want_intermediates:
+        res.update(flags=flags, feat_cc=feat_cc, feat_pp=feat_pp, ceps_cum=ccum, n_ceps=n_ceps, first_out=first,
+                   onset=onset, den_f32=f32)
+    return res
+
+
 def rfft_batch(frames):
     """frames: float32 tensor [n,256] on the GPU -> rfft of every row."""
     torch = _torch()

@@ -412,3 +412,49 @@ def test_selftest_div_by_middle_ear_gain():
     assert sea.load().sea_selftest_div(out) == 0
     assert out[1] == 2 * (200 * (1 << 23) + 1)           # both signs: exponents -100..99 in full, plus |a| = 2^100
     assert out[0] == 0, f"{out[0]} mismatching quotients"
+
+
+def test_afe_feature_chain_vs_oracle(oracle):
+    """NoiseSup -> WaveProc -> CompCeps -> PostProc -> VAD (+ flush), the chain the
+    reference author commented out (ParmInterface.c:274-311).  The oracle for it is pinned bit-exact
+    against the reference's own functions (tests/test_oracle.py); the GPU must reproduce the per-frame
+    speech flags and VAD decisions exactly and the features within the CompCeps tolerance (1e-3)."""
+    import speech_enhancement_amd as sea
+    _torch()
+    utts = _mixed_corpus()
+    utts.append(np.zeros(480, np.int16))
+    from speech_enhancement_amd import corpus
+    utts.append(corpus.synth_utterance(31, 32000))
+    batch = sea.PackedBatch.from_arrays(utts)
+    res = sea.afe_features_batch(batch, want_intermediates=True)
+    flags = res["flags"].cpu().numpy()
+    fcc, fpp = res["feat_cc"].cpu().numpy(), res["feat_pp"].cpu().numpy()
+    n_ceps, first = res["n_ceps"].cpu().numpy(), res["first_out"].cpu().numpy()
+    worst = 0.0
+    for u, x in enumerate(utts):
+        tr = oracle.afe_trace(x)
+        assert int(n_ceps[u]) == tr["nceps"], f"utt {u}"
+        # speech flags per NoiseSup output frame
+        nfr = len(x) // 80
+        if tr["nout"]:
+            f0 = int(first[u])
+            got = flags[batch.host_offsets[u] // 8 + 10 * np.arange(f0, nfr)]
+            want = tr["flags"][f0:nfr, :4] @ np.array([1, 2, 4, 8])
+            assert np.array_equal(got, want), f"utt {u}: speech flags differ at {np.nonzero(got != want)[0][:5]}"
+        c0 = res["ceps_cum"][u]
+        if tr["nceps"]:
+            for name, g, w in (("feat_cc", fcc, tr["feat_cc"]), ("feat_pp", fpp, tr["feat_pp"])):
+                d = float(np.abs(g[c0:c0 + tr["nceps"]] - w).max())
+                worst = max(worst, d)
+                assert d <= 1e-3, f"utt {u} {name}: off by {d}"
+        got15 = res["feats"][u]
+        assert got15.shape == tr["vad_out"].shape, f"utt {u}: {got15.shape} vs {tr['vad_out'].shape}"
+        if len(got15):
+            assert np.array_equal(got15[:, 14], tr["vad_out"][:, 14]), f"utt {u}: VAD flags differ"
+            d = float(np.abs(got15[:, :14] - tr["vad_out"][:, :14]).max())
+            worst = max(worst, d)
+            assert d <= 1e-3, f"utt {u} emitted features: off by {d}"
+    print("AFE chain worst |delta| =", worst)
+    # the audio is the same as the plain NoiseSup kernel's
+    plain, _, _ = sea.ns_denoise_batch(batch)
+    assert _torch().equal(plain, res["out"])
