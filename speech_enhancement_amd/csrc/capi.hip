@@ -211,7 +211,7 @@ int sea_afe_features_batch(const float *d_den_f32, const unsigned char *d_flags,
     a.tables = c->cc;
     a.n_utt = n_utt;
     if (total_ceps > 0) {
-        const long long want = total_ceps < (1LL << 20) ? total_ceps : (1LL << 20);
+        const long long want = total_ceps < 65536 ? total_ceps : 65536; /* >= 12 frames per wave at configs[1]: amortises the table loads */
         hipLaunchKernelGGL(sea::afe_ceps_kernel, dim3((unsigned)want), dim3(64), 0, (hipStream_t)stream, a);
         HIP_TRY(hipGetLastError());
     }

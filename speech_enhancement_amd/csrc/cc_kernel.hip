@@ -201,19 +201,31 @@ struct __attribute__((aligned(16))) WpLds {
     int pos[24];
 };
 
-/* wave-wide arg-max of (value, index) pairs; ties go to the LOWER index if lowWins, else the higher.
- * Entries with valid == false never win.  Returns the winning index, -1 if none is valid. */
+/* wave-wide maximum of a signed 32-bit value in 6 DPP steps (row_shr 1/2/4/8 within rows of 16
+ * lanes, then row_bcast 15 / 31 across rows: the total lands in lane 63); a ds_bpermute butterfly
+ * costs an LDS round trip per step instead */
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    constexpr int kMin = -2147483647 - 1;
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    v = mx(v, __builtin_amdgcn_update_dpp(kMin, v, 0x111, 0xf, 0xf, false)); /* row_shr:1 */
+    v = mx(v, __builtin_amdgcn_update_dpp(kMin, v, 0x112, 0xf, 0xf, false)); /* row_shr:2 */
+    v = mx(v, __builtin_amdgcn_update_dpp(kMin, v, 0x114, 0xf, 0xf, false)); /* row_shr:4 */
+    v = mx(v, __builtin_amdgcn_update_dpp(kMin, v, 0x118, 0xf, 0xf, false)); /* row_shr:8 */
+    v = mx(v, __builtin_amdgcn_update_dpp(kMin, v, 0x142, 0xa, 0xf, false)); /* row_bcast:15 -> rows 1, 3 */
+    v = mx(v, __builtin_amdgcn_update_dpp(kMin, v, 0x143, 0xc, 0xf, false)); /* row_bcast:31 -> rows 2, 3 */
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+/* wave-wide arg-max of (value >= 0, index < 256) pairs; ties go to the LOWER index if lowWins, else
+ * the higher.  Entries with valid == false never win.  Returns the winning index, -1 if none. */
 __device__ __forceinline__ int wave_argmax(int value, int index, bool valid, bool lowWins)
 {
-    int bv = value, bi = valid ? index : -1;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const int ov = __shfl_xor(bv, off, 64), oi = __shfl_xor(bi, off, 64);
-        const bool take = (oi >= 0) && ((bi < 0) || (ov > bv) || (ov == bv && (lowWins ? (oi < bi) : (oi > bi))));
-        bv = take ? ov : bv;
-        bi = take ? oi : bi;
-    }
-    return bi;
+    const int m = wave_max_i32(valid ? value : -1);
+    if (m < 0) return -1;
+    const int code = (valid && value == m) ? (lowWins ? 255 - index : index) : -1;
+    const int c = wave_max_i32(code);
+    return lowWins ? 255 - c : c;
 }
 
 /* DoWaveProc (WaveProc.c:397-455) on W.frame[1..200], in place: Teager energy (:216-226), its 9-point
@@ -327,12 +339,16 @@ __device__ __forceinline__ void waveproc_frame(WpLds &W, float *sq, int lane)
     for (int k = 0; k < 4; ++k) {
         const int j = lane + 64 * k;
         if (j < N) {
+            /* the raised segments [pos_i - 4, pos_i - 4 + ceil(0.8 gap_i)) are ordered and disjoint: the only
+             * one that can hold j is the last one starting at or before j */
             bool high = false;
             if (nom > 1) {
-                for (int i = 0; i < nom; ++i) {
-                    const int a = W.pos[i] - 4;
+                int cnt = 0;
+                for (int i = 0; i < nom; ++i) cnt += (W.pos[i] - 4 <= j) ? 1 : 0;
+                if (cnt > 0) {
+                    const int i = cnt - 1;
                     const int gap = (i < nom - 1) ? (W.pos[i + 1] - W.pos[i]) : (W.pos[nom - 1] - W.pos[nom - 2]);
-                    high |= (j >= a) && (j < a + (80 * gap + 99) / 100);
+                    high = j < W.pos[i] - 4 + (80 * gap + 99) / 100;
                 }
             }
             W.tw[j] = high ? highVal : lowVal;
@@ -454,9 +470,27 @@ __global__ __launch_bounds__(64) void afe_vad_kernel(AfeArgs a)
         if (lane == 14) feat = (vCount || hCount || trigger >= 3) ? 1.0f : 0.0f;
     };
 
-    for (long long j = 0; j < nceps; ++j) {
+    /* rows and flag bytes are requested kAhead frames before use: the loop body is a few dozen
+     * instructions, an HBM round trip a few thousand clocks */
+    constexpr int kAhead = 8;
+    float rowQ[kAhead];
+    int bitQ[kAhead];
+    auto fetch = [&](long long j, float &row, int &bits) {
+        const long long jj = j < nceps ? j : (nceps > 0 ? nceps - 1 : 0);
+        row = (lane < 14 && nceps > 0) ? cc[jj * SEA_CC_NCEP + lane] : 0.0f;
+        bits = (nceps > 0) ? (int)flg[10 * (f0 + jj + 2)] : 0;
+    };
+#pragma unroll
+    for (int q = 0; q < kAhead; ++q) fetch(q, rowQ[q], bitQ[q]);
+    for (long long j0 = 0; j0 < nceps; j0 += kAhead) {
+#pragma unroll
+      for (int q = 0; q < kAhead; ++q) {
+        const long long j = j0 + q;
+        if (j >= nceps) break;
         /* PostProc on c1..c12; the weighting comes from logE = Coef[13] (Noc0 == 0) */
-        const float c = (lane < 14) ? cc[j * SEA_CC_NCEP + lane] : 0.0f;
+        const float c = rowQ[q];
+        const int bits = bitQ[q];
+        fetch(j + kAhead, rowQ[q], bitQ[q]);
         const float logE = __shfl(c, 13, 64);
         float wp = (logE * (float)64 - (float)211) / (float)64;
         wp = (wp < 0) ? 0.0f : ((wp > 1) ? lambda : wp * lambda);
@@ -471,7 +505,6 @@ __global__ __launch_bounds__(64) void afe_vad_kernel(AfeArgs a)
         /* DoVADProc */
         frameCounter = (int)j + 5; /* nbFrame[0] when NoiseSup output j+3 appears */
         focus = (focus + 1 == 7) ? 0 : focus + 1;
-        const int bits = flg[10 * (f0 + j + 2)];
         if (lane < 14) ring[focus][lane] = feat;
         if (lane == 14) ring[focus][14] = bits ? 1.0f : 0.0f;
         wave_sync();
@@ -481,6 +514,7 @@ __global__ __launch_bounds__(64) void afe_vad_kernel(AfeArgs a)
             nemit++;
         }
         wave_sync();
+      }
     }
     /* FlushAdvProcess until DoVADFlush returns FALSE */
     {

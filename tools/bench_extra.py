@@ -40,7 +40,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--utts", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--what", default="resynth,ibm,subband,ceps,rfft,host")
+    ap.add_argument("--what", default="resynth,ibm,subband,ceps,afe,rfft,host")
     args = ap.parse_args()
     import torch
     import speech_enhancement_amd as sea
@@ -103,6 +103,46 @@ def main():
                           "roofline": {"bound": "hbm", "kernel": "sea::compceps_kernel", "achieved": alg / ker / 1e9,
                                        "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / ker / 1e9 / HBM_PEAK_GBPS,
                                        "algorithmic_bytes_per_step": alg, "avg_step_ms": ker * 1e3}}), flush=True)
+
+    if "afe" in what:
+        # NoiseSup (with speech flags) -> WaveProc -> CompCeps -> PostProc -> VAD + flush
+        lib = sea.load()
+        n = batch.n_utt
+        outb = torch.zeros_like(batch.data)
+        f32 = torch.zeros(batch.total, dtype=torch.float32, device=dev)
+        first = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        onset = torch.zeros(n, dtype=torch.int32, device=dev)
+        flags = torch.zeros(batch.total // 8, dtype=torch.uint8, device=dev)
+        nfr = np.asarray(batch.host_lengths) // 80
+        ccum = np.concatenate(([0], np.cumsum(np.maximum(nfr - 6, 0)))).astype(np.int64)
+        fcum = np.concatenate(([0], np.cumsum(nfr + 6))).astype(np.int64)
+        tc, tf = int(ccum[-1]), int(fcum[-1])
+        fcc = torch.zeros((tc, 14), dtype=torch.float32, device=dev)
+        f15 = torch.zeros((tf, 15), dtype=torch.float32, device=dev)
+        nfe = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_ccum, d_fcum = torch.from_numpy(ccum).to(dev), torch.from_numpy(fcum).to(dev)
+        P = lambda t: t.data_ptr()
+        st = torch.cuda.current_stream().cuda_stream
+
+        def ns_fd():
+            assert lib.sea_ns_denoise_batch_fd(P(batch.data), P(outb), P(f32), P(batch.offsets), P(batch.lengths),
+                                               P(batch.order), P(first), P(flags), P(onset), n, st) == 0
+
+        def feats():
+            assert lib.sea_afe_features_batch(P(f32), P(flags), P(batch.offsets), P(batch.lengths), P(first), P(onset),
+                                              P(d_ccum), tc, P(fcc), None, P(d_fcum), P(f15), P(nfe), None, n, st) == 0
+        w1, k1 = timed(ns_fd, args.steps)
+        w2, k2 = timed(feats, args.steps)
+        emitted = int(nfe.sum().item())
+        alg = batch.n_frames * 320 + emitted * 60
+        print(json.dumps({"metric": "ETSI AFE feature frames/sec (NoiseSup + WaveProc + CompCeps + PostProc + VAD)",
+                          "value": emitted / (w1 + w2), "unit": "feature frames/s", "ms_per_step": (w1 + w2) * 1e3,
+                          "config": {"workload": f"SURVEY 8(f) #3: {n} utterances, {emitted} emitted feature frames of 15 floats",
+                                     "ns_with_flags_ms": k1 * 1e3, "waveproc_compceps_postproc_vad_ms": k2 * 1e3},
+                          "roofline": {"bound": "hbm", "kernels": "sea::ns_denoise_pipe_fd_kernel + sea::afe_ceps_kernel + sea::afe_vad_kernel",
+                                       "achieved": alg / (k1 + k2) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                       "frac": alg / (k1 + k2) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": alg,
+                                       "avg_step_ms": (k1 + k2) * 1e3}}), flush=True)
 
     if "host" in what:
         # the host-buffer drop-in path: pack + hipMalloc + H2D + one launch + D2H (PCIe inclusive)
