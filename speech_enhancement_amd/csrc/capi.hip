@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -39,6 +40,7 @@ struct DeviceCtx {
     sea_ns_tables *ns = nullptr;
     sea_cc_tables *cc = nullptr;
     sea_gt_tables *gt = nullptr;
+    int n_cu = 256;
 };
 
 constexpr int kMaxDev = 64;
@@ -71,6 +73,7 @@ int ctx(DeviceCtx **out)
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail("device %d is %s; this library is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+        c.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         host_tables();
         HIP_TRY(hipMalloc(&c.ns, sizeof(sea_ns_tables)));
         HIP_TRY(hipMalloc(&c.cc, sizeof(sea_cc_tables)));
@@ -92,6 +95,84 @@ struct DevBuf {
 };
 
 long long align8(long long v) { return (v + 7) & ~7LL; }
+
+/* Grow-only workspace of the host-buffer entry points, one per calling host thread (the reference's
+ * Windows batch tool calls etsi_denoise from N threads): pinned staging, device buffers, a private
+ * stream.  A drop-in call then costs copies + one launch, no hipMalloc / hipFree. */
+struct HostWs {
+    short *h_in = nullptr, *h_out = nullptr; /* pinned */
+    short *d_in = nullptr, *d_out = nullptr;
+    long long *h_meta = nullptr, *d_meta = nullptr; /* offsets | lengths */
+    int *h_order = nullptr, *d_order = nullptr;
+    size_t cap = 0, cap_utt = 0;
+    hipStream_t stream = nullptr;
+    ~HostWs() { release(); }
+    void release()
+    {
+        if (h_in) (void)hipHostFree(h_in);
+        if (h_out) (void)hipHostFree(h_out);
+        if (h_meta) (void)hipHostFree(h_meta);
+        if (h_order) (void)hipHostFree(h_order);
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        if (d_meta) (void)hipFree(d_meta);
+        if (d_order) (void)hipFree(d_order);
+        h_in = h_out = d_in = d_out = nullptr;
+        h_meta = d_meta = nullptr;
+        h_order = d_order = nullptr;
+        cap = cap_utt = 0;
+    }
+    hipError_t ensure(size_t samples, size_t n_utt)
+    {
+        hipError_t e;
+        if (!stream && (e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return e;
+        if (samples > cap) {
+            const size_t want = samples + samples / 4 + 4096;
+            if (h_in) (void)hipHostFree(h_in);
+            if (h_out) (void)hipHostFree(h_out);
+            if (d_in) (void)hipFree(d_in);
+            if (d_out) (void)hipFree(d_out);
+            h_in = h_out = d_in = d_out = nullptr;
+            cap = 0;
+            if ((e = hipHostMalloc((void **)&h_in, want * sizeof(short), hipHostMallocDefault)) != hipSuccess) return e;
+            if ((e = hipHostMalloc((void **)&h_out, want * sizeof(short), hipHostMallocDefault)) != hipSuccess) return e;
+            if ((e = hipMalloc((void **)&d_in, want * sizeof(short) + 16)) != hipSuccess) return e;
+            if ((e = hipMalloc((void **)&d_out, want * sizeof(short) + 16)) != hipSuccess) return e;
+            cap = want;
+        }
+        if (n_utt > cap_utt) {
+            const size_t want = n_utt + n_utt / 4 + 16;
+            if (h_meta) (void)hipHostFree(h_meta);
+            if (h_order) (void)hipHostFree(h_order);
+            if (d_meta) (void)hipFree(d_meta);
+            if (d_order) (void)hipFree(d_order);
+            h_meta = d_meta = nullptr;
+            h_order = d_order = nullptr;
+            cap_utt = 0;
+            if ((e = hipHostMalloc((void **)&h_meta, 2 * want * sizeof(long long), hipHostMallocDefault)) != hipSuccess) return e;
+            if ((e = hipHostMalloc((void **)&h_order, want * sizeof(int), hipHostMallocDefault)) != hipSuccess) return e;
+            if ((e = hipMalloc((void **)&d_meta, 2 * want * sizeof(long long))) != hipSuccess) return e;
+            if ((e = hipMalloc((void **)&d_order, want * sizeof(int))) != hipSuccess) return e;
+            cap_utt = want;
+        }
+        return hipSuccess;
+    }
+};
+thread_local HostWs t_ws;
+
+/* launch order of the utterance-per-workgroup kernels: longest first, every other row of n_cu reversed
+ * (workgroups b, b + n_cu, ... share a CU; see speech_enhancement_amd/engine.py::launch_order) */
+void launch_order(const long long *lens, int n, int n_cu, int *order)
+{
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+    for (int start = 0, row = 0; start < n; start += n_cu, ++row) {
+        const int end = start + n_cu < n ? start + n_cu : n;
+        if (row & 1) std::reverse(idx.begin() + start, idx.begin() + end);
+    }
+    for (int i = 0; i < n; ++i) order[i] = idx[i];
+}
 
 } // namespace
 
@@ -271,32 +352,37 @@ int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const
 int sea_denoise_utterances(const short *const *in, short *const *out, const long *lengths, int n_utt)
 {
     if (n_utt <= 0) return 0;
-    std::vector<long long> offs(n_utt), lens(n_utt);
+    DeviceCtx *dc;
+    if (ctx(&dc)) return 1;
     long long total = 0;
     for (int u = 0; u < n_utt; ++u) {
         if (lengths[u] < 0) return fail("negative length for utterance %d", u);
-        offs[u] = total;
-        lens[u] = lengths[u];
         total += align8(lengths[u]);
     }
     if (total == 0) return 0;
-    std::vector<short> pack((size_t)total, 0);
-    for (int u = 0; u < n_utt; ++u) memcpy(&pack[(size_t)offs[u]], in[u], (size_t)lens[u] * sizeof(short));
-
-    DevBuf<short> din, dout;
-    DevBuf<long long> doffs, dlens;
-    HIP_TRY(din.alloc((size_t)total));
-    HIP_TRY(dout.alloc((size_t)total));
-    HIP_TRY(doffs.alloc(n_utt));
-    HIP_TRY(dlens.alloc(n_utt));
-    HIP_TRY(hipMemcpy(din.p, pack.data(), (size_t)total * sizeof(short), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(doffs.p, offs.data(), n_utt * sizeof(long long), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dlens.p, lens.data(), n_utt * sizeof(long long), hipMemcpyHostToDevice));
-    if (sea_ns_denoise_batch(din.p, dout.p, nullptr, doffs.p, dlens.p, nullptr, nullptr, n_utt, nullptr)) return 1;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(pack.data(), dout.p, (size_t)total * sizeof(short), hipMemcpyDeviceToHost));
+    HostWs &w = t_ws;
+    HIP_TRY(w.ensure((size_t)total, (size_t)n_utt));
+    long long *offs = w.h_meta, *lens = w.h_meta + n_utt;
+    long long pos = 0;
+    for (int u = 0; u < n_utt; ++u) {
+        offs[u] = pos;
+        lens[u] = lengths[u];
+        memcpy(w.h_in + pos, in[u], (size_t)lens[u] * sizeof(short));
+        const long long pad = align8(lens[u]) - lens[u];
+        if (pad) memset(w.h_in + pos + lens[u], 0, (size_t)pad * sizeof(short));
+        pos += align8(lens[u]);
+    }
+    launch_order(lens, n_utt, dc->n_cu, w.h_order);
+    HIP_TRY(hipMemcpyAsync(w.d_in, w.h_in, (size_t)total * sizeof(short), hipMemcpyHostToDevice, w.stream));
+    HIP_TRY(hipMemcpyAsync(w.d_meta, w.h_meta, 2 * (size_t)n_utt * sizeof(long long), hipMemcpyHostToDevice, w.stream));
+    HIP_TRY(hipMemcpyAsync(w.d_order, w.h_order, (size_t)n_utt * sizeof(int), hipMemcpyHostToDevice, w.stream));
+    if (sea_ns_denoise_batch(w.d_in, w.d_out, nullptr, w.d_meta, w.d_meta + n_utt, n_utt > 1 ? w.d_order : nullptr,
+                             nullptr, n_utt, w.stream))
+        return 1;
+    HIP_TRY(hipMemcpyAsync(w.h_out, w.d_out, (size_t)total * sizeof(short), hipMemcpyDeviceToHost, w.stream));
+    HIP_TRY(hipStreamSynchronize(w.stream));
     for (int u = 0; u < n_utt; ++u) /* the trailing partial frame stays untouched */
-        memcpy(out[u], &pack[(size_t)offs[u]], (size_t)(lens[u] / 80 * 80) * sizeof(short));
+        memcpy(out[u], w.h_out + offs[u], (size_t)(lens[u] / 80 * 80) * sizeof(short));
     return 0;
 }
 
