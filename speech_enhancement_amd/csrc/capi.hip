@@ -561,7 +561,7 @@ int sea_subband64_batch(const short *d_in, short *d_out, const long long *d_offs
     a.order = d_order;
     a.tables = c->gt;
     a.n_utt = n_utt;
-    hipLaunchKernelGGL(sea::subband_kernel, dim3(n_utt), dim3(320), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(sea::subband_kernel, dim3(n_utt), dim3(384), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -36,15 +36,11 @@ namespace sea {
 
 namespace {
 
-/* timing-only diagnostic: bit k set = role k of the tile pipelines skips its work (results wrong) */
-#ifndef SEA_RS_SKIP
-#define SEA_RS_SKIP 0
-#endif
 
 /* timing-only diagnostic (-DSEA_RS_TIMING): per role, shader-clock cycles spent working and waiting
  * at the tile barrier, for workgroup 0 -> g_rs_timing[kernel*6 + role*2 + {0,1}] */
 #ifdef SEA_RS_TIMING
-__device__ unsigned long long g_rs_timing[16]; /* fwd R1,R2,H = 0..5; bwd R1,R2,W,SUM = 6..13 */
+__device__ unsigned long long g_rs_timing[32]; /* fwd R1,R2,R3 = 0..5; bwd R1,R2,W,SUM = 6..13; subband R1,R2,K,HC,W = 16..25 */
 struct RoleTimer {
     unsigned long long work = 0, wait = 0, t0 = 0, t1 = 0;
     __device__ __forceinline__ void begin() { t0 = clock64(); }
@@ -303,7 +299,7 @@ __global__ __launch_bounds__(192, 3) void resynth_fwd_kernel(ResynthArgs a)
         feed.start(in, L, lane); /* extractwav.cpp:55-58 */
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
-            if (j < ntile && !(SEA_RS_SKIP & 1)) {
+            if (j < ntile) {
                 feed.tile(in, L, j, lane, xs);
                 wave_sync();
                 v2f(*o)[64] = pq[j & 1];
@@ -326,7 +322,7 @@ __global__ __launch_bounds__(192, 3) void resynth_fwd_kernel(ResynthArgs a)
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
             const long long jt = j - 1;
-            if (jt >= 0 && jt < ntile && !(SEA_RS_SKIP & 2)) {
+            if (jt >= 0 && jt < ntile) {
                 const v2f(*i)[64] = pq[jt & 1];
                 v2f(*o)[64] = pa[jt & 1];
 #pragma unroll
@@ -350,7 +346,7 @@ __global__ __launch_bounds__(192, 3) void resynth_fwd_kernel(ResynthArgs a)
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
             const long long jt = j - 2;
-            if (jt >= 0 && jt < ntile && !(SEA_RS_SKIP & 4)) {
+            if (jt >= 0 && jt < ntile) {
                 const v2f(*i)[64] = pa[jt & 1];
                 float *row = dst + jt * (kTile * 64);
                 float gv[kTile], v[kTile];
@@ -449,7 +445,7 @@ __global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
                 const long long j = j0 + m;
                 if (j >= niter) break;
                 RS_T_BEGIN;
-                if (j < ntile && !(SEA_RS_SKIP & 1)) {
+                if (j < ntile) {
                     v2f(*o)[64] = pq[j & 1];
                     /* step t of this pass = step 15-t of the stored tile: quarters 3..0, each w,z,y,x */
 #pragma unroll
@@ -480,7 +476,7 @@ __global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
             const long long jt = j - 1;
-            if (jt >= 0 && jt < ntile && !(SEA_RS_SKIP & 2)) {
+            if (jt >= 0 && jt < ntile) {
                 const v2f(*i)[64] = pq[jt & 1];
                 float *o = gp[buf] + lane;
 #pragma unroll
@@ -521,7 +517,7 @@ __global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
             const long long jt = j - 2;
-            if (jt >= 0 && jt < ntile && !(SEA_RS_SKIP & 4)) {
+            if (jt >= 0 && jt < ntile) {
                 float *g = gp[buf] + lane;
                 float gv[kTile], v[kTile];
 #pragma unroll
@@ -579,7 +575,7 @@ __global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
             const long long jt = j - 3;
-            if (jt >= 0 && jt < ntile && !(SEA_RS_SKIP & 8)) {
+            if (jt >= 0 && jt < ntile) {
                 if (lane < kTile) { /* channel sum in order 0..63 for step t = lane, (short) cast :120-121 */
                     const long long m = mTop - jt * kTile - lane;
                     const float4 *row = reinterpret_cast<const float4 *>(gp[buf] + lane * kTileStride);
@@ -608,10 +604,10 @@ __global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
  * gammatone -> Meddis hair cell -> (short) cast -> 64 int16 streams per utterance
  * (enhancement_extract_test/cpp/extractwav.cpp:40-101; hairCell resyth_64sub_ori/cpp/extractwav.cpp:
  * 212-257, constants HuWang.h:36-44).  Output is 64x the input: 128 B written per input sample, the
- * one genuinely HBM-write-heavy kernel of the path.  Workgroup = one utterance = five waves,
+ * one genuinely HBM-write-heavy kernel of the path.  Workgroup = one utterance = six waves,
  * lane = channel, 16-sample tiles:
  *   R1, R2  the two halves of the gammatone cascade (as in the resynthesis kernels)
- *   K       the hair cell's input-only permeability kt (a double division per sample)
+ *   K0, K1  the hair cell's input-only permeability kt (a double division per sample), even / odd steps
  *   HC      the q/c/w recurrence, output hdt*c truncated to int16 into a padded LDS tile
  *   W       transposes the tile (lane = 16 samples x 4 channels) and streams 32-byte runs of each
  *           channel's row; consecutive tiles complete the 128-byte lines in L2. */
@@ -667,7 +663,7 @@ constexpr int kSbStride = 66; /* int16 per tile row: 64 channels + 2 pad (33 wor
 
 } // namespace
 
-__global__ __launch_bounds__(320) void subband_kernel(SubbandArgs a)
+__global__ __launch_bounds__(384) void subband_kernel(SubbandArgs a)
 {
     __shared__ RsLds S;
     __shared__ __attribute__((aligned(16))) float xs[kTile];
@@ -678,6 +674,7 @@ __global__ __launch_bounds__(320) void subband_kernel(SubbandArgs a)
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long off = a.offsets[u], L = a.lengths[u];
     const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 4;
+    RS_T_DECL;
     if (role == 0) {
         const int16_t *in = a.in + off;
         const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
@@ -685,6 +682,7 @@ __global__ __launch_bounds__(320) void subband_kernel(SubbandArgs a)
         InFeed feed;
         feed.start(in, L, lane);
         for (long long j = 0; j < niter; ++j) {
+            RS_T_BEGIN;
             if (j < ntile) {
                 feed.tile(in, L, j, lane, xs);
                 wave_sync();
@@ -697,13 +695,17 @@ __global__ __launch_bounds__(320) void subband_kernel(SubbandArgs a)
                 }
                 wave_sync();
             }
+            RS_T_MID;
             tile_sync();
+            RS_T_END;
         }
+        RS_T_FLUSH(16);
     } else if (role == 1) {
         const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
         const float gain = a.tables->gain[lane];
         GtHi s = {};
         for (long long j = 0; j < niter; ++j) {
+            RS_T_BEGIN;
             const long long jt = j - 1;
             if (jt >= 0 && jt < ntile) {
                 const v2f(*i)[64] = S.pq[jt & 1];
@@ -711,27 +713,37 @@ __global__ __launch_bounds__(320) void subband_kernel(SubbandArgs a)
 #pragma unroll
                 for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_hi(s, i[t][lane], C, gain);
             }
+            RS_T_MID;
             tile_sync();
+            RS_T_END;
         }
-    } else if (role == 2) {
-        /* K: the hair cell's permeability, input-only (16 independent double divisions per tile) */
+        RS_T_FLUSH(18);
+    } else if (role == 2 || role == 3) {
+        /* K (two waves, even / odd steps): the hair cell's permeability, input-only; a correctly rounded
+         * double division per sample is ~35 dependent instructions, the longest stage by far */
         HairCell h;
         haircell_init(h);
+        const int par = role - 2;
         for (long long j = 0; j < niter; ++j) {
+            RS_T_BEGIN;
             const long long jt = j - 2;
             if (jt >= 0 && jt < ntile) {
                 const float(*g)[64] = S.g[jt & 1];
                 float(*o)[64] = ktile[jt & 1];
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) o[t][lane] = haircell_kt(h, g[t][lane]);
+                for (int t = 0; t < kTile; t += 2) o[t + par][lane] = haircell_kt(h, g[t + par][lane]);
             }
+            RS_T_MID;
             tile_sync();
+            RS_T_END;
         }
-    } else if (role == 3) {
+        RS_T_FLUSH(20);
+    } else if (role == 4) {
         /* HC: the q/c/w recurrence and the (short) cast of hOut (extractwav.cpp:85-88) */
         HairCell h;
         haircell_init(h);
         for (long long j = 0; j < niter; ++j) {
+            RS_T_BEGIN;
             const long long jt = j - 3;
             if (jt >= 0 && jt < ntile) {
                 const float(*k)[64] = ktile[jt & 1];
@@ -739,14 +751,18 @@ __global__ __launch_bounds__(320) void subband_kernel(SubbandArgs a)
 #pragma unroll
                 for (int t = 0; t < kTile; ++t) o[t * kSbStride + lane] = (short)cast_i16(haircell_step(h, k[t][lane]));
             }
+            RS_T_MID;
             tile_sync();
+            RS_T_END;
         }
+        RS_T_FLUSH(22);
     } else {
         /* W: lane = sample t (0..15) of channel group cg (0..3): 16 passes cover the 64 channels */
         int16_t *out = a.out + off * 64;
         const long long Lp = (L + 7) & ~7LL; /* row pitch of this utterance's [64][Lp] block */
         const int t = lane & 15, cg = lane >> 4;
         for (long long j = 0; j < niter; ++j) {
+            RS_T_BEGIN;
             const long long jt = j - 4;
             if (jt >= 0 && jt < ntile) {
                 const long long n = jt * kTile + t;
@@ -759,8 +775,11 @@ __global__ __launch_bounds__(320) void subband_kernel(SubbandArgs a)
                     }
                 }
             }
+            RS_T_MID;
             tile_sync();
+            RS_T_END;
         }
+        RS_T_FLUSH(24);
     }
 }
 
@@ -795,6 +814,6 @@ __global__ __launch_bounds__(256) void selftest_div_kernel(const sea_gt_tables *
 #ifdef SEA_RS_TIMING
 extern "C" int sea_debug_rs_timing(unsigned long long *out16)
 {
-    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(sea::g_rs_timing), 16 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(sea::g_rs_timing), 32 * sizeof(unsigned long long));
 }
 #endif

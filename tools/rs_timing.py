@@ -20,13 +20,16 @@ def main():
         masks = sea.MaskBatch.from_arrays([mask1] * n, dev)
         for _ in range(2):
             sea.resynth_batch(batch, masks)
+            sea.subband_batch(batch)
         torch.cuda.synchronize()
-        t = (ctypes.c_ulonglong * 16)()
+        t = (ctypes.c_ulonglong * 32)()
         assert lib.sea_debug_rs_timing(t) == 0
         tiles = L / 16
         names = ["fwd R1", "fwd R2", "fwd R3", "bwd R1", "bwd R2", "bwd W", "bwd SUM"]
         print(json.dumps({"n_utt": n, **{nm: {"work_cyc_per_tile": round(t[2 * i] / tiles), "wait_cyc_per_tile": round(t[2 * i + 1] / tiles)}
-                                         for i, nm in enumerate(names)}}), flush=True)
+                                         for i, nm in enumerate(names)},
+                          **{nm: {"work_cyc_per_tile": round(t[16 + 2 * i] / tiles), "wait_cyc_per_tile": round(t[17 + 2 * i] / tiles)}
+                             for i, nm in enumerate(["sb R1", "sb R2", "sb K", "sb HC", "sb W"])}}), flush=True)
 
 
 if __name__ == "__main__":
