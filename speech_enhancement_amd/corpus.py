@@ -64,3 +64,36 @@ def synth_corpus(n_utt, first=0, max_len=None):
             L = min(L, int(max_len))
         out.append(synth_utterance(u, L))
     return out
+
+
+def write_mask_text(f, utt_id, mask):
+    """One Kaldi-style 64-column text matrix, byte for byte what the reference's make_single_IBM prints
+    (enhancement_extract_test/cpp/show_IBM.cpp:194-208) and what its resynth driver parses
+    (resyth_64sub_ori/cpp/main.cpp:84-145): SURVEY 8(f) #2."""
+    mask = np.asarray(mask, dtype=np.float32)
+    assert mask.ndim == 2 and mask.shape[1] == 64 and len(mask) >= 1
+    f.write(f"{utt_id} [\n")
+    for row in mask[:-1]:
+        f.write("".join("%.7f " % v for v in row) + "\n ")
+    f.write("".join("%.7f " % v for v in mask[-1]) + "]\n")
+
+
+def read_mask_text(f):
+    """Generator of (utt_id, float32 [rows,64]) from a text file of such matrices."""
+    utt_id, rows = None, []
+    for line in f:
+        if "[" in line:
+            if utt_id is not None:
+                yield utt_id, np.asarray(rows, dtype=np.float32).reshape(-1, 64)
+            utt_id, rows = line.split("[")[0].strip(), []
+        elif utt_id is not None:
+            vals = []
+            for tok in line.split():
+                try:
+                    vals.append(float(tok))
+                except ValueError:
+                    break
+            if vals:
+                rows.append((vals + [0.0] * 64)[:64])
+    if utt_id is not None:
+        yield utt_id, np.asarray(rows, dtype=np.float32).reshape(-1, 64)

@@ -150,3 +150,53 @@ int sea_wav_write(const char *path, const short *data, long n, int fs)
     fclose(fp);
     return 0;
 }
+
+/* ---- Kaldi-style 64-column text matrices (show_IBM.cpp:194-208 writer, main.cpp:84-145 reader) ---- */
+int sea_mask_text_write(FILE *fp, const char *id, const float *mask64, long rows)
+{
+    long f;
+    int c;
+    if (!fp || rows < 1) return 1;
+    fprintf(fp, "%s [\n", id);
+    for (f = 0; f < rows - 1; f++) {
+        for (c = 0; c < 64; c++) fprintf(fp, "%.7f ", mask64[f * 64 + c]);
+        fprintf(fp, "\n ");
+    }
+    for (c = 0; c < 64; c++) fprintf(fp, "%.7f ", mask64[(rows - 1) * 64 + c]);
+    fprintf(fp, "]\n");
+    return ferror(fp) ? 1 : 0;
+}
+
+long sea_mask_text_read(FILE *fp, char *id_out, float *mask64, long max_rows)
+{
+    char buf[64 * 32];
+    long row = -1;
+    while (1) {
+        long pos = ftell(fp);
+        if (!fgets(buf, sizeof buf, fp)) break;
+        if (strstr(buf, "[")) {
+            if (row >= 0) { /* the next matrix begins: leave its header for the next call */
+                fseek(fp, pos, SEEK_SET);
+                break;
+            }
+            if (id_out) {
+                size_t n = strcspn(buf, " \t[");
+                if (n >= SEA_FILE_LEN) n = SEA_FILE_LEN - 1;
+                memcpy(id_out, buf, n);
+                id_out[n] = 0;
+            }
+            row = 0;
+        } else if (row >= 0 && row < max_rows) {
+            char *p = buf, *end;
+            int j;
+            for (j = 0; j < 64; j++) {
+                float v = strtof(p, &end);
+                if (end == p) break;
+                mask64[row * 64 + j] = v;
+                p = end;
+            }
+            if (j > 0) row++;
+        }
+    }
+    return row;
+}

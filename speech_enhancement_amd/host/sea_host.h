@@ -34,4 +34,15 @@ void sea_free_list(char **ids, int n);
 int sea_wav_read(const char *path, short **data, long *n, int *fs);
 int sea_wav_write(const char *path, const short *data, long n, int fs);
 
+/* SURVEY 8(f) #2 -- the on-disk contract between feature extraction, the external DNN and resynth:
+ * Kaldi-style text matrices of 64 columns.  sea_mask_text_write emits exactly what make_single_IBM
+ * prints (enhancement_extract_test/cpp/show_IBM.cpp:194-208): "<id> [\n", rows of "%.7f " joined
+ * by "\n ", "]\n" after the last row.  sea_mask_text_read parses the next matrix the way
+ * resyth_64sub_ori/cpp/main.cpp:84-145 does (a line containing '[' opens a matrix, every other line
+ * contributes up to 64 floats, text after them -- the closing ']' -- is ignored); it fills at most
+ * max_rows rows and returns the number of rows read, -1 at end of file. */
+#include <stdio.h>
+int sea_mask_text_write(FILE *fp, const char *id, const float *mask64, long rows);
+long sea_mask_text_read(FILE *fp, char *id_out /* SEA_FILE_LEN, may be NULL */, float *mask64, long max_rows);
+
 #endif

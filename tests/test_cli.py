@@ -108,11 +108,9 @@ def test_cli_resynth_end_to_end(tmp_path, oracle, ibm):
     utts = [corpus.synth_utterance(30 + k, 1600 + 240 * k) for k in range(3)]
     masks = [corpus.synth_mask(30 + k, len(x)) for k, x in enumerate(utts)]
     out, ids = _workspace(tmp_path, utts, with_nummix=False)
-    with open(out + "result.txt", "w") as f:           # Kaldi-style text matrices
+    with open(out + "result.txt", "w") as f:           # Kaldi-style text matrices, the reference writer's bytes
         for i, m in zip(ids, masks):
-            f.write(f"{i}  [\n")
-            for r_, row in enumerate(m):
-                f.write("  " + " ".join(f"{v:.7f}" for v in row) + (" ]\n" if r_ == len(m) - 1 else " \n"))
+            corpus.write_mask_text(f, i, m)
     exe = "enhance_resyth_subband_IBM" if ibm else "enhance_resyth_subband"
     r = subprocess.run([os.path.join(BIN, exe), out + "cfg.txt"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr + r.stdout

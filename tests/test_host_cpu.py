@@ -176,3 +176,71 @@ def test_sharding_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_mask_text_format_roundtrip(tmp_path):
+    """the Kaldi-style text matrix between feature extraction, the DNN and resynth
+    (writer enhancement_extract_test/cpp/show_IBM.cpp:194-208, reader resyth_64sub_ori/cpp/main.cpp:
+    84-145).  The C writer of the host library and the Python mirror emit the same bytes; the C
+    reader gets the %.7f-rounded values back, matrix after matrix."""
+    import subprocess
+    from speech_enhancement_amd import corpus
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "speech_enhancement_amd", "host")
+    drv = tmp_path / "drv.c"
+    drv.write_text(r'''
+#include "sea_host.h"
+#include <stdlib.h>
+#include <string.h>
+int main(int argc, char **argv)
+{   /* drv <bin-in> <txt-out> <bin-back>: n matrices of [rows][64] floats with ids u0, u1, ... */
+    FILE *bi = fopen(argv[1], "rb"), *tx = fopen(argv[2], "w"), *bo;
+    int n, u; long rows[16]; float *m[16]; char id[SEA_FILE_LEN];
+    fread(&n, sizeof n, 1, bi);
+    for (u = 0; u < n; u++) {
+        fread(&rows[u], sizeof rows[u], 1, bi);
+        m[u] = malloc(rows[u] * 64 * sizeof(float));
+        fread(m[u], sizeof(float), rows[u] * 64, bi);
+        sprintf(id, "u%d", u);
+        if (sea_mask_text_write(tx, id, m[u], rows[u])) return 1;
+    }
+    fclose(tx);
+    tx = fopen(argv[2], "r");
+    bo = fopen(argv[3], "wb");
+    for (u = 0; u < n; u++) {
+        float *back = calloc(rows[u] * 64, sizeof(float));
+        long got = sea_mask_text_read(tx, id, back, rows[u]);
+        char want[16]; sprintf(want, "u%d", u);
+        if (got != rows[u] || strcmp(id, want)) return 2;
+        fwrite(back, sizeof(float), rows[u] * 64, bo);
+    }
+    if (sea_mask_text_read(tx, id, m[0], 1) != -1) return 3;
+    return 0;
+}
+''')
+    exe = tmp_path / "drv"
+    subprocess.run(["gcc", "-O1", "-std=gnu99", "-I", host, "-o", str(exe), str(drv), os.path.join(host, "sea_host.c")],
+                   check=True)
+    rng = np.random.default_rng(4)
+    mats = [rng.random((r, 64)).astype(np.float32) for r in (1, 2, 9)]
+    mats[1][0, :3] = [0.0, 1.0, 0.5]
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(np.int32(len(mats)).tobytes())
+        for m in mats:
+            f.write(np.int64(len(m)).tobytes())
+            f.write(m.tobytes())
+    subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "m.txt"), str(tmp_path / "back.bin")], check=True)
+    with open(tmp_path / "py.txt", "w") as f:
+        for u, m in enumerate(mats):
+            corpus.write_mask_text(f, f"u{u}", m)
+    assert (tmp_path / "m.txt").read_bytes() == (tmp_path / "py.txt").read_bytes()
+    text = (tmp_path / "m.txt").read_text()
+    assert text.startswith("u0 [\n") and text.endswith(" ]\n") and "\n u" not in text
+    back = np.fromfile(tmp_path / "back.bin", dtype=np.float32)
+    want = np.concatenate([np.array([[float("%.7f" % v) for v in row] for row in m], np.float32).ravel() for m in mats])
+    assert np.array_equal(back, want)
+    with open(tmp_path / "m.txt") as f:
+        got = list(corpus.read_mask_text(f))
+    assert [g[0] for g in got] == ["u0", "u1", "u2"]
+    assert all(np.array_equal(g[1].ravel(), want[o:o + m.size]) for g, m, o in
+               zip(got, mats, np.cumsum([0] + [m.size for m in mats[:-1]])))
