@@ -458,3 +458,34 @@ def test_afe_feature_chain_vs_oracle(oracle):
     # the audio is the same as the plain NoiseSup kernel's
     plain, _, _ = sea.ns_denoise_batch(batch)
     assert _torch().equal(plain, res["out"])
+
+
+def test_etsi_denoise_from_concurrent_host_threads(oracle):
+    """The reference's batch tool calls etsi_denoise() from N host threads
+    (function/20141106_speech_enhancement/aurora_speech_enhancement/aurora_speech_enhancement.cpp:111-121):
+    the drop-in keeps a workspace and a stream per calling thread, results stay exact."""
+    import threading
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    _torch()
+    utts = [corpus.synth_utterance(60 + k, 2400 + 800 * (k % 5)) for k in range(16)]
+    want = [oracle.etsi_denoise(x, fill=-7777) for x in utts]
+    got = [None] * len(utts)
+    errs = []
+
+    def work(tid):
+        try:
+            for rep in range(3):
+                for k in range(tid, len(utts), 4):
+                    got[k] = sea.etsi_denoise(utts[k], fill=-7777)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for k in range(len(utts)):
+        assert np.array_equal(got[k], want[k]), f"utterance {k}"
