@@ -425,8 +425,7 @@ __device__ __forceinline__ float ns_mel_fb(const BackLds &B, const NsConst &C, i
  * lanes 0..39 produce two outputs each into dst.  Ends with wave_sync().
  * LDSBASIS: the 9x25 basis sits in LDS ([f][16], lane = row) instead of 25 VGPRs per lane. */
 template <bool LDSBASIS>
-__device__ __forceinline__ void ns_idct_fir(float melOut, BackLds &B, const NsConst &C, const float *buf,
-                                            float *dst, int lane, const float *idctLds)
+__device__ __forceinline__ void ns_idct_taps(float melOut, BackLds &B, const NsConst &C, int lane, const float *idctLds)
 {
     if (lane < SEA_NMEL) B.mel[lane] = melOut;
     wave_sync();
@@ -446,37 +445,50 @@ __device__ __forceinline__ void ns_idct_fir(float melOut, BackLds &B, const NsCo
         B.fir[8 - lane] = tap;
     }
     wave_sync();
-    {
-        float c[SEA_NTAP]; /* the taps are wave-uniform: broadcast LDS reads */
+}
+
+/* ApplyWF (NoiseSup.c:324-340): the 17 taps fir[0..16] (wave-uniform: broadcast LDS reads) over
+ * buf[80..159] with 8 samples of context either side; lanes 0..39 produce two outputs each into dst.
+ * Ends with wave_sync(). */
+__device__ __forceinline__ void ns_fir_apply(const float *fir, const float *buf, float *dst, int lane)
+{
+    float c[SEA_NTAP];
 #pragma unroll
-        for (int k4 = 0; k4 < 16; k4 += 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(&B.fir[k4]);
-            c[k4] = v.x;
-            c[k4 + 1] = v.y;
-            c[k4 + 2] = v.z;
-            c[k4 + 3] = v.w;
+    for (int k4 = 0; k4 < 16; k4 += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(&fir[k4]);
+        c[k4] = v.x;
+        c[k4 + 1] = v.y;
+        c[k4 + 2] = v.z;
+        c[k4 + 3] = v.w;
+    }
+    c[16] = fir[16];
+    if (lane < 40) {
+        float x[18];
+        const float *src = buf + 72 + 2 * lane; /* x[m] = buf[72 + 2l + m] */
+#pragma unroll
+        for (int m = 0; m < 18; m += 2) {
+            const float2 v = *reinterpret_cast<const float2 *>(src + m);
+            x[m] = v.x;
+            x[m + 1] = v.y;
         }
-        c[16] = B.fir[16];
-        if (lane < 40) {
-            float x[18];
-            const float *src = buf + 72 + 2 * lane; /* x[m] = buf[72 + 2l + m] */
+        float y0 = 0.0f, y1 = 0.0f;
+        /* out[i] = sum_{j=-8..8} fir[j+8] * buf[80+i-j]; i = 2l -> buf index 72+2l+(8-j) */
 #pragma unroll
-            for (int m = 0; m < 18; m += 2) {
-                const float2 v = *reinterpret_cast<const float2 *>(src + m);
-                x[m] = v.x;
-                x[m + 1] = v.y;
-            }
-            float y0 = 0.0f, y1 = 0.0f;
-            /* out[i] = sum_{j=-8..8} fir[j+8] * buf[80+i-j]; i = 2l -> buf index 72+2l+(8-j) */
-#pragma unroll
-            for (int k = 0; k < SEA_NTAP; ++k) {
-                y0 += c[k] * x[16 - k];
-                y1 += c[k] * x[17 - k];
-            }
-            *reinterpret_cast<float2 *>(dst + 2 * lane) = make_float2(y0, y1);
+        for (int k = 0; k < SEA_NTAP; ++k) {
+            y0 += c[k] * x[16 - k];
+            y1 += c[k] * x[17 - k];
         }
+        *reinterpret_cast<float2 *>(dst + 2 * lane) = make_float2(y0, y1);
     }
     wave_sync();
+}
+
+template <bool LDSBASIS>
+__device__ __forceinline__ void ns_idct_fir(float melOut, BackLds &B, const NsConst &C, const float *buf,
+                                            float *dst, int lane, const float *idctLds)
+{
+    ns_idct_taps<LDSBASIS>(melOut, B, C, lane, idctLds);
+    ns_fir_apply(B.fir, buf, dst, lane);
 }
 
 /* BACK half of a stage (ST = 0 first, 1 second): everything recursive.  Consumes psd[0..64] and
@@ -486,8 +498,10 @@ __device__ __forceinline__ void ns_idct_fir(float melOut, BackLds &B, const NsCo
  * PIPE = true (pipelined kernel): the input-only / deferrable scalar chains run in a helper wave.
  *   ST 0: the VAD frame log-energy arrives in frameEnExt; the 65 denSigSE1 values go to spectOut
  *         (summed later by the helper), the denEn registers are not touched.
- *   ST 1: the caller has loaded s.denEn0..2. */
-template <int ST, bool PIPE, bool FD = false>
+ *   ST 1: the caller has loaded s.denEn0..2.
+ * DEFER_FIR: stop after the IDCT and deposit the 17 filter taps in dst[0..16]; the FIR itself is then
+ *   run by the consumer wave (ns_fir_apply), which has cycles to spare. */
+template <int ST, bool PIPE, bool FD = false, bool DEFER_FIR = false>
 __device__ __forceinline__ void ns_back(const float *psd, const float *buf, BackLds &B, NsRegs &s,
                                         const NsConst &C, float *dst, int lane, float frameEnExt = 0.0f,
                                         float *spectOut = nullptr, const float *idctLds = nullptr,
@@ -561,7 +575,13 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
             melOut = (float)((double)(s.alfaGF * melOut) + (1.0 - (double)s.alfaGF) * 1.0);
         }
     }
-    ns_idct_fir<PIPE>(melOut, B, C, buf, dst, lane, idctLds);
+    if (DEFER_FIR) { /* the consumer wave applies the filter (ns_fir_apply): hand over the 17 taps */
+        ns_idct_taps<PIPE>(melOut, B, C, lane, idctLds);
+        if (lane < SEA_NTAP) dst[lane] = B.fir[lane];
+        wave_sync();
+    } else {
+        ns_idct_fir<PIPE>(melOut, B, C, buf, dst, lane, idctLds);
+    }
 }
 
 /* One whole stage on the single-wave form: stage 0 deposits its 80 output samples in
@@ -632,42 +652,50 @@ __device__ __forceinline__ bool dc_filter(const float *dif, float *out, float &y
     return redo;
 }
 
-/* The three lane-redundant in-order chains of the helper wave, advanced TOGETHER: a wave64 issues a
- * dependent vector instruction every 8 clk but independent ones every 4-5 (tools/lat_probe.hip), so
- * interleaving the VAD sum (64 + sum sq[0..79]), the denSigSE1 sum (den[0..64]) and the DC-offset
- * recurrence (dif[0..79] -> out[0..79], float FMA form of dc_filter) costs little more than the
- * longest of them alone.  All three are always computed; the caller discards what it does not
- * need (the arrays are always readable).  Ends with wave_sync(). */
+/* The three in-order chains of the helper wave -- the VAD sum (64 + sum sq[0..79]), the denSigSE1 sum
+ * (den[0..64]) and the DC-offset recurrence (dif[0..79] -> out[0..79], float-FMA form of dc_filter) --
+ * advanced by ONE instruction stream, each in its own group of lanes: every step is
+ *     acc = fma(m, acc, x[n])      m = 1 for the sums (RN(1*acc + x) == RN(acc + x)), 1023/1024 for DC
+ * with per-lane source / destination pointers (lanes 0-15 | 16-31 | 32-63).  A wave64 issues a
+ * dependent vector instruction every 8 clk whatever the number of active lanes, so the three
+ * 65..80-step chains cost 80 dependent FMAs instead of 225 dependent operations.  den[65..67] must be
+ * zero (they are: the record is cleared once and only [0..64] is ever written); zero4: four zero
+ * floats; junk: 160 floats of scratch for the partial sums of the two sum groups.  All three are always computed; the caller
+ * discards what it does not need.  Ends with wave_sync(). */
 __device__ __forceinline__ void helper_chains(const float *sq, const float *den, const float *dif, float *out,
-                                              float &vadSum, float &denSum, float &y)
+                                              float *junk, const float *zero4, float &vadSum, float &denSum,
+                                              float &y, int lane)
 {
-    float a = 64.0f, b = 0.0f;
-#pragma unroll 4
-    for (int n = 0; n < 64; n += 4) {
-        const float4 s4 = *reinterpret_cast<const float4 *>(&sq[n]);
-        const float4 e4 = *reinterpret_cast<const float4 *>(&den[n]);
-        const float4 d4 = *reinterpret_cast<const float4 *>(&dif[n]);
-        float4 o;
-        a += s4.x; b += e4.x; y = __fmaf_rn(0.9990234375f, y, d4.x); o.x = y;
-        a += s4.y; b += e4.y; y = __fmaf_rn(0.9990234375f, y, d4.y); o.y = y;
-        a += s4.z; b += e4.z; y = __fmaf_rn(0.9990234375f, y, d4.z); o.z = y;
-        a += s4.w; b += e4.w; y = __fmaf_rn(0.9990234375f, y, d4.w); o.w = y;
-        *reinterpret_cast<float4 *>(&out[n]) = o;
-    }
-    b += den[64];
+    const int g = lane >> 4;
+    const float *src = (g == 0) ? sq : ((g == 1) ? den : dif);
+    const float *tail = (g == 1) ? zero4 : src; /* the den chain runs out after 65 terms: x = 0 from n = 68 on */
+    float *dst = (g == 0) ? junk : ((g == 1) ? junk + SEA_HOP : out);
+    const float m = (g >= 2) ? 0.9990234375f : 1.0f;
+    float acc = (g == 0) ? 64.0f : ((g == 1) ? 0.0f : y);
+    /* all 20 quads are requested before the chain starts (80 VGPRs, the helper wave has them to spare):
+     * an LDS round trip is ~60 clk, eight dependent-FMA slots */
+    float4 x[SEA_HOP / 4];
 #pragma unroll
-    for (int n = 64; n < SEA_HOP; n += 4) {
-        const float4 s4 = *reinterpret_cast<const float4 *>(&sq[n]);
-        const float4 d4 = *reinterpret_cast<const float4 *>(&dif[n]);
-        float4 o;
-        a += s4.x; y = __fmaf_rn(0.9990234375f, y, d4.x); o.x = y;
-        a += s4.y; y = __fmaf_rn(0.9990234375f, y, d4.y); o.y = y;
-        a += s4.z; y = __fmaf_rn(0.9990234375f, y, d4.z); o.z = y;
-        a += s4.w; y = __fmaf_rn(0.9990234375f, y, d4.w); o.w = y;
-        *reinterpret_cast<float4 *>(&out[n]) = o;
+    for (int k = 0; k < SEA_HOP / 4; ++k) {
+        const int n = 4 * k;
+        x[k] = *reinterpret_cast<const float4 *>((n >= 68) ? tail + ((g == 1) ? 0 : n) : src + n);
     }
-    vadSum = a;
-    denSum = b;
+#pragma unroll
+    for (int k = 0; k < SEA_HOP / 4; ++k) {
+        float4 o;
+        acc = __fmaf_rn(m, acc, x[k].x);
+        o.x = acc;
+        acc = __fmaf_rn(m, acc, x[k].y);
+        o.y = acc;
+        acc = __fmaf_rn(m, acc, x[k].z);
+        o.z = acc;
+        acc = __fmaf_rn(m, acc, x[k].w);
+        o.w = acc;
+        *reinterpret_cast<float4 *>(dst + 4 * k) = o;
+    }
+    vadSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
+    denSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 16));
+    y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 32));
     wave_sync();
 }
 

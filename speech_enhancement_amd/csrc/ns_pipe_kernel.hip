@@ -11,11 +11,11 @@
  *            BOTH front halves side by side in one dual transform (lanes 0..31 / 32..63):
  *            window+rfft+PSD of stage 0 for frame i and of stage 1 for frame i-2
  *   wave B0  frame i-1   stage-0 FilterCalc, mel, IDCT, 17-tap FIR  -> stage-1 buffer
- *   wave B1  frame i-3   stage-1 FilterCalc, gain factorisation, mel, IDCT, FIR
+ *   wave B1  frame i-3   stage-1 FilterCalc, gain factorisation, mel, IDCT (its FIR runs in S)
  *   wave S   the lane-redundant scalar chains that need no lane parallelism and are either
  *            input-only or deferrable:  VAD frame log-energy of the frame pushed at i-1 (consumed
  *            by B0 two frames later), in-order sum of denSigSE1 of frame i-2 (consumed by B1),
- *            DC-offset recurrence + int16 cast + store of frame i-4.
+ *            stage-1 FIR, DC-offset recurrence + int16 cast + store of frame i-4.
  *
  * Front halves depend only on the sample buffers; all recursive state lives in the registers of B0,
  * B1 and S.  The two 320-sample stage buffers of the reference (NoiseSup.c:98-99) become 8-slot
@@ -39,6 +39,11 @@ constexpr int kMirror = 3 * kSlotLen;      /* slots 0..2 repeated behind the end
 constexpr int kPipeWaves = 4;
 
 /* timing-only diagnostic: bit set = that piece of work is done (default all) */
+/* 1: the second-stage FIR runs in the helper wave S instead of B1 (shorter lone-workgroup frame period,
+ * slightly more instructions) */
+#ifndef SEA_FIR_IN_S
+#define SEA_FIR_IN_S 1
+#endif
 #ifndef SEA_ROLE_MASK
 #define SEA_ROLE_MASK 127
 #endif
@@ -95,7 +100,8 @@ struct __attribute__((aligned(16))) Rec23 { /* F -> B1 */
     int valid, tick, pad0, pad1;
 };
 struct __attribute__((aligned(16))) Rec34 { /* B1 -> S */
-    float out[80]; /* second-stage filter output before the DC-offset filter */
+    float fir[20]; /* SEA_FIR_IN_S: the 17 taps of the second-stage filter, S applies them */
+    float out[80]; /* otherwise: second-stage filter output before the DC-offset filter */
     int produced, tick, pad1, pad2;
 };
 
@@ -104,6 +110,9 @@ struct __attribute__((aligned(16))) PipeLds {
     float work[512];                /* the two FFT frames of F */
     BackLds back[2];                /* scratch of B0 and B1 */
     float ssq[80], sdif[80], sout[80]; /* scratch of S */
+    float sjunk[160];               /* partial sums of S's two sum chains (never read) */
+    float szero[4];                 /* zeros: what the shorter chain reads past its end */
+    float sfir[80];                 /* second-stage filter output before the DC-offset filter */
     float frameEn[kSlots];          /* VAD log-energy for tick t at [t & 7] */
     float denSum[kSlots];           /* sum of denSigSE1 of tick t at [t & 7] */
     int fdFlags[kSlots];            /* speech flags of tick t at [t & 7] (frame-dropping VAD variant) */
@@ -165,6 +174,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
 
     for (int i = threadIdx.x; i < 2 * (kCirc + kMirror); i += 64 * kPipeWaves) (&L.circ[0][0])[i] = 0.0f;
     for (int i = threadIdx.x; i < SEA_NMEL * 16; i += 64 * kPipeWaves) L.idctT[i] = a.tables->idct[i >> 4][i & 15];
+    if (threadIdx.x < 4) L.szero[threadIdx.x] = 0.0f;
     if (threadIdx.x < kSlots) {
         L.frameEn[threadIdx.x] = 0.0f;
         L.denSum[threadIdx.x] = 0.0f;
@@ -172,6 +182,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
     if (threadIdx.x < 2) {
         L.r01[threadIdx.x].valid = 0;
         L.r12[threadIdx.x].valid = 0;
+        L.r12[threadIdx.x].den[65] = L.r12[threadIdx.x].den[66] = L.r12[threadIdx.x].den[67] = 0.0f; /* read as zeros by S */
         L.r23[threadIdx.x].valid = 0;
         L.r34[threadIdx.x].produced = 0;
     }
@@ -295,8 +306,8 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                     s.denEn0 = L.denSum[(t - 2) & (kSlots - 1)];
                     s.denEn1 = L.denSum[(t - 1) & (kSlots - 1)];
                     s.denEn2 = L.denSum[t & (kSlots - 1)];
-                    ns_back<1, true>(r.psd, L.circ[1] + window_base(t), L.back[1], s, C, o.out, lane, 0.0f, nullptr,
-                                     L.idctT);
+                    ns_back<1, true, false, SEA_FIR_IN_S != 0>(r.psd, L.circ[1] + window_base(t), L.back[1], s, C,
+                                                               SEA_FIR_IN_S ? o.fir : o.out, lane, 0.0f, nullptr, L.idctT);
                     produced = 1;
                 }
                 if (lane == 0) {
@@ -352,18 +363,20 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                     L.ssq[64 + lane] = yv * yv;
                 }
             }
-            if (produced) {
+            if (produced) { /* stage-1 17-tap FIR (NoiseSup.c:324-340), then the DC differences */
                 const Rec34 &r = L.r34[fo & 1];
-                const float xm1 = (lane == 0) ? dcX : r.out[lane - 1];
-                L.sdif[lane] = r.out[lane] - xm1;
-                if (lane < 16) L.sdif[64 + lane] = r.out[64 + lane] - r.out[63 + lane];
-                dcX = r.out[79];
+                if (SEA_FIR_IN_S) ns_fir_apply(r.fir, L.circ[1] + window_base(r.tick), L.sfir, lane);
+                const float *y2 = SEA_FIR_IN_S ? L.sfir : r.out;
+                const float xm1 = (lane == 0) ? dcX : y2[lane - 1];
+                L.sdif[lane] = y2[lane] - xm1;
+                if (lane < 16) L.sdif[64 + lane] = y2[64 + lane] - y2[63 + lane];
+                dcX = y2[79];
             }
             NS_T_CK(0);
             if (doVad || doDen || produced) {
                 wave_sync();
                 float vadSum, denTotal, y = dcY;
-                helper_chains(L.ssq, denSrc, L.sdif, L.sout, vadSum, denTotal, y);
+                helper_chains(L.ssq, denSrc, L.sdif, L.sout, L.sjunk, L.szero, vadSum, denTotal, y, lane);
                 NS_T_CK(1);
                 if (doVad) {
                     const float en = vad_frame_energy(vadSum);
