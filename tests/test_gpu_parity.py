@@ -489,3 +489,17 @@ def test_etsi_denoise_from_concurrent_host_threads(oracle):
     assert not errs, errs
     for k in range(len(utts)):
         assert np.array_equal(got[k], want[k]), f"utterance {k}"
+
+
+def test_frame_counter_int16_wrap(oracle):
+    """An utterance longer than 32767 frames: the reference's int16 narrowing of the frame counter in
+    FilterCalc is reproduced (the oracle is checked against the reference on the same
+    input in tests/test_oracle.py)."""
+    import speech_enhancement_amd as sea
+    from tests.test_oracle import _long_utterance
+    _torch()
+    x = _long_utterance()
+    got = sea.etsi_denoise(x)
+    want = oracle.etsi_denoise(x)
+    _assert_int16_close(got, want, "33100-frame utterance")
+    assert np.array_equal(got, want)
