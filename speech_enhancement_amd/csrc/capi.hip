@@ -473,9 +473,19 @@ int sea_resynth64_batch(const short *d_in, short *d_out, const long long *d_offs
     a.tables = c->gt;
     a.n_utt = n_utt;
     a.binary = binary;
-    hipLaunchKernelGGL(sea::resynth_fwd_kernel, dim3(n_utt), dim3(192), 0, (hipStream_t)stream, a);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(sea::resynth_bwd_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
+    /* default: both passes of an utterance in one workgroup; SEA_RESYNTH=split selects the two-launch form
+     * (analysis pass of the whole batch, then synthesis pass; identical results) */
+    static const bool split = [] {
+        const char *e = getenv("SEA_RESYNTH");
+        return e && !strcmp(e, "split");
+    }();
+    if (split) {
+        hipLaunchKernelGGL(sea::resynth_fwd_kernel, dim3(n_utt), dim3(192), 0, (hipStream_t)stream, a);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(sea::resynth_bwd_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(sea::resynth_fused_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -280,18 +280,26 @@ struct __attribute__((aligned(16))) RsLds {
 
 /* Analysis pass: three waves per utterance (R1 stages 0-1 | R2 stage 2 | R3 stage 3, division by the
  * middle-ear gain, HBM store), 16-step tiles, one barrier per tile. */
-__global__ __launch_bounds__(192, 3) void resynth_fwd_kernel(ResynthArgs a)
+namespace {
+
+struct __attribute__((aligned(16))) FwdLds {
+    v2f pq[2][kTile][64]; /* R1 -> R2: new (p1,q1) */
+    v2f pa[2][kTile][64]; /* R2 -> R3: partial sums A */
+    float xs[kTile];
+};
+
+/* roles 0..2 work; any further wave of the workgroup only keeps the barrier count (fused kernel) */
+__device__ __forceinline__ void resynth_fwd_body(const ResynthArgs &a, FwdLds &S, int role, int lane, int u,
+                                                 long long off, long long L)
 {
-    __shared__ __attribute__((aligned(16))) v2f pq[2][kTile][64]; /* R1 -> R2: new (p1,q1) */
-    __shared__ __attribute__((aligned(16))) v2f pa[2][kTile][64]; /* R2 -> R3: partial sums A */
-    __shared__ __attribute__((aligned(16))) float xs[kTile];
-    const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    const long long off = a.offsets[u], L = a.lengths[u];
+    v2f(*pq)[kTile][64] = S.pq;
+    v2f(*pa)[kTile][64] = S.pa;
+    float *xs = S.xs;
     const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 2;
     RS_T_DECL;
-    if (role == 0) {
+    if (role > 2) {
+        for (long long j = 0; j < niter; ++j) tile_sync();
+    } else if (role == 0) {
         const int16_t *in = a.in + off;
         const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
         GtLo s = {};
@@ -365,6 +373,17 @@ __global__ __launch_bounds__(192, 3) void resynth_fwd_kernel(ResynthArgs a)
     }
 }
 
+} // namespace
+
+__global__ __launch_bounds__(192, 3) void resynth_fwd_kernel(ResynthArgs a)
+{
+    __shared__ FwdLds S;
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    resynth_fwd_body(a, S, role, lane, u, a.offsets[u], a.lengths[u]);
+}
+
 /* gammaToneFilter() for one channel of the bank (HuWang.h:49): a serial recurrence, one lane. */
 __global__ __launch_bounds__(64) void gammatone_kernel(const float *in, float *out, int chan, long long L,
                                                        const sea_gt_tables *t)
@@ -388,20 +407,34 @@ __global__ __launch_bounds__(64) void gammatone_kernel(const float *in, float *o
  *   SUM lane = step: the 64 channel terms added in channel order (a 64-deep dependent chain, which
  *       is why it has a wave of its own), (short) cast, store
  * The g / product tile passes through three owners (R2, W, SUM), hence three buffers. */
-__global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
+namespace {
+
+struct __attribute__((aligned(16))) BwdLds {
+    v2f pq[2][kTile][64];             /* R1 -> R2 */
+    float gp[3][kTile * kTileStride]; /* R2 -> W -> SUM */
+    double olaUp[160], olaDown[160];
+    float wbin[4][160]; /* binary masks: the only four weight curves there are (none | falling | rising | both) */
+};
+
+/* four waves; the caller has excluded L < 320 (no mask frame fits) */
+__device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S, int role, int lane, int u,
+                                                 long long off, long long L)
 {
-    __shared__ __attribute__((aligned(16))) v2f pq[2][kTile][64];          /* R1 -> R2 */
-    __shared__ __attribute__((aligned(16))) float gp[3][kTile * kTileStride]; /* R2 -> W -> SUM */
-    __shared__ double olaUp[160], olaDown[160];
-    const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    const long long off = a.offsets[u], L = a.lengths[u];
-    if (L < 320) return; /* no mask frame fits (wave-uniform exit before any barrier) */
+    v2f(*pq)[kTile][64] = S.pq;
+    float(*gp)[kTile * kTileStride] = S.gp;
+    double *olaUp = S.olaUp, *olaDown = S.olaDown;
     const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 3;
     for (int i = threadIdx.x; i < 160; i += 256) {
-        olaUp[i] = a.tables->olaUp[i];
-        olaDown[i] = a.tables->olaDown[i];
+        const double up = a.tables->olaUp[i], down = a.tables->olaDown[i];
+        olaUp[i] = up;
+        olaDown[i] = down;
+        /* with mask values in {0, 1} the weight of a sample is one of four floats that depend on its
+         * position in the hop only: (float)(0 + down*1), (float)(0 + up*1), (float)((double)(float)down + up*1) */
+        const float wd = (float)(down * 1.0);
+        S.wbin[0][i] = 0.0f;
+        S.wbin[1][i] = wd;
+        S.wbin[2][i] = (float)((double)0.0f + up * 1.0);
+        S.wbin[3][i] = (float)((double)wd + up * 1.0);
     }
     tile_sync();
 
@@ -529,13 +562,19 @@ __global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
                      * accumulation needs no add. */
                     const double mhD = (double)mh, mh1D = (double)mh1;
                     const bool useH = mh > 0.0f, useH1 = mh1 > 0.0f;
+                    if (binary) { /* IBM variant: table look-up instead of the double-precision products */
+                        const float *tab = S.wbin[(useH ? 1 : 0) | (useH1 ? 2 : 0)] + r;
 #pragma unroll
-                    for (int t = 0; t < kTile; ++t) {
-                        const float w1 = (float)(olaDown[r - t] * mhD);
-                        float w = useH ? w1 : 0.0f;
-                        const float w2 = (float)((double)w + olaUp[r - t] * mh1D);
-                        w = useH1 ? w2 : w;
-                        g[t * kTileStride] = w * v[t]; /* :108-112 term of this channel */
+                        for (int t = 0; t < kTile; ++t) g[t * kTileStride] = tab[-t] * v[t];
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < kTile; ++t) {
+                            const float w1 = (float)(olaDown[r - t] * mhD);
+                            float w = useH ? w1 : 0.0f;
+                            const float w2 = (float)((double)w + olaUp[r - t] * mh1D);
+                            w = useH1 ? w2 : w;
+                            g[t * kTileStride] = w * v[t]; /* :108-112 term of this channel */
+                        }
                     }
                     r -= kTile;
                     if (r < 0) { /* step into hop h-1 */
@@ -598,6 +637,43 @@ __global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
         }
         RS_T_FLUSH(12);
     }
+}
+
+} // namespace
+
+__global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
+{
+    __shared__ BwdLds S;
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    const long long L = a.lengths[u];
+    if (L < 320) return; /* no mask frame fits (wave-uniform exit before any barrier) */
+    resynth_bwd_body(a, S, role, lane, u, a.offsets[u], L);
+}
+
+/* Both passes of one utterance in ONE workgroup, back to back: the analysis pass of the long
+ * utterances no longer has to drain (and idle most of the chip) before any synthesis pass may
+ * start -- a workgroup that finishes its analysis moves straight on, so the two tails overlap with
+ * other utterances' work.  The intermediate still goes through HBM (the synthesis pass reads it
+ * backwards); the hand-over inside the workgroup is a release / acquire pair at agent scope. */
+__global__ __launch_bounds__(256, 4) void resynth_fused_kernel(ResynthArgs a)
+{
+    __shared__ union U {
+        FwdLds f;
+        BwdLds b;
+        __device__ U() {}
+    } S;
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    const long long off = a.offsets[u], L = a.lengths[u];
+    if (L < 320) return;
+    resynth_fwd_body(a, S.f, role, lane, u, off, L);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    resynth_bwd_body(a, S.b, role, lane, u, off, L);
 }
 
 /* ---- subbband() -- the analysis half on its own --------------------------------

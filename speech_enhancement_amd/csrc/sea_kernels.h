@@ -113,6 +113,7 @@ __global__ void compceps_frames_kernel(const float *data201, float *coef14, long
                                        const sea_cc_tables *t);
 __global__ void resynth_fwd_kernel(ResynthArgs a);
 __global__ void resynth_bwd_kernel(ResynthArgs a);
+__global__ void resynth_fused_kernel(ResynthArgs a); /* both passes of an utterance in one workgroup */
 __global__ void gammatone_kernel(const float *in, float *out, int chan, long long L, const sea_gt_tables *t);
 
 } // namespace sea
