@@ -674,24 +674,33 @@ __device__ __forceinline__ void helper_chains(const float *sq, const float *den,
     float acc = (g == 0) ? 64.0f : ((g == 1) ? 0.0f : y);
     /* all 20 quads are requested before the chain starts (80 VGPRs, the helper wave has them to spare):
      * an LDS round trip is ~60 clk, eight dependent-FMA slots */
-    float4 x[SEA_HOP / 4];
+#ifndef SEA_CHAIN_CHUNKS
+#define SEA_CHAIN_CHUNKS 4 /* quads requested per group: 20 / 4 = 5 (20 VGPRs).  1 chunk (80 VGPRs) is ~1 % faster at four
+                              * workgroups per CU but caps the occupancy there; 4 chunks: 296 vs 267 M frames/s at 8192 utterances */
+#endif
+    constexpr int kQ = SEA_HOP / 4 / SEA_CHAIN_CHUNKS;
 #pragma unroll
-    for (int k = 0; k < SEA_HOP / 4; ++k) {
-        const int n = 4 * k;
-        x[k] = *reinterpret_cast<const float4 *>((n >= 68) ? tail + ((g == 1) ? 0 : n) : src + n);
-    }
+    for (int c = 0; c < SEA_CHAIN_CHUNKS; ++c) {
+        float4 x[kQ];
 #pragma unroll
-    for (int k = 0; k < SEA_HOP / 4; ++k) {
-        float4 o;
-        acc = __fmaf_rn(m, acc, x[k].x);
-        o.x = acc;
-        acc = __fmaf_rn(m, acc, x[k].y);
-        o.y = acc;
-        acc = __fmaf_rn(m, acc, x[k].z);
-        o.z = acc;
-        acc = __fmaf_rn(m, acc, x[k].w);
-        o.w = acc;
-        *reinterpret_cast<float4 *>(dst + 4 * k) = o;
+        for (int k = 0; k < kQ; ++k) {
+            const int n = 4 * (c * kQ + k);
+            x[k] = *reinterpret_cast<const float4 *>((n >= 68) ? tail + ((g == 1) ? 0 : n) : src + n);
+        }
+#pragma unroll
+        for (int k = 0; k < kQ; ++k) {
+            float4 o;
+            acc = __fmaf_rn(m, acc, x[k].x);
+            o.x = acc;
+            acc = __fmaf_rn(m, acc, x[k].y);
+            o.y = acc;
+            acc = __fmaf_rn(m, acc, x[k].z);
+            o.z = acc;
+            acc = __fmaf_rn(m, acc, x[k].w);
+            o.w = acc;
+            *reinterpret_cast<float4 *>(dst + 4 * (c * kQ + k)) = o;
+        }
+        if (c + 1 < SEA_CHAIN_CHUNKS) __builtin_amdgcn_sched_barrier(0);
     }
     vadSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
     denSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 16));

@@ -44,6 +44,10 @@ constexpr int kPipeWaves = 4;
 #ifndef SEA_FIR_IN_S
 #define SEA_FIR_IN_S 1
 #endif
+/* waves per SIMD the register allocation must leave room for (= workgroups per CU of this 4-wave kernel) */
+#ifndef SEA_NS_MIN_WAVES
+#define SEA_NS_MIN_WAVES 4
+#endif
 #ifndef SEA_ROLE_MASK
 #define SEA_ROLE_MASK 127
 #endif
@@ -416,11 +420,11 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
     }
 }
 
-__global__ __launch_bounds__(256, 4) void ns_denoise_pipe_kernel(NsBatchArgs a) { ns_pipe_body<false>(a); }
+__global__ __launch_bounds__(256, SEA_NS_MIN_WAVES) void ns_denoise_pipe_kernel(NsBatchArgs a) { ns_pipe_body<false>(a); }
 
 /* the same pipeline with the first stage's speech measures (SpeechQVar/Spec/Mel, VADNS) evaluated in
  * B0 and their four bits stored per output frame: input of the frame-dropping VAD */
-__global__ __launch_bounds__(256, 4) void ns_denoise_pipe_fd_kernel(NsBatchArgs a) { ns_pipe_body<true>(a); }
+__global__ __launch_bounds__(256, SEA_NS_MIN_WAVES) void ns_denoise_pipe_fd_kernel(NsBatchArgs a) { ns_pipe_body<true>(a); }
 
 } // namespace sea
 
