@@ -110,7 +110,9 @@ int sea_afe_features_batch(const float *d_den_f32, const unsigned char *d_flags,
  * d_mask_offsets[u] and number (lengths[u]-320)/160+1.  d_inter is scratch of
  * sea_resynth_scratch_bytes(total padded samples of the batch, n_utt) bytes (the [time][64]
  * float intermediate between the two passes, ~256 B per sample: it is what 288 GB of HBM is
- * for).  binary != 0 selects the ideal-binary-mask variant. */
+ * for).  binary: bit 0 selects the ideal-binary-mask variant (resyth_64sub_IBM); bit 1 the older
+ * driver's frame count, lengths[u]/160 mask rows per utterance instead of (lengths[u]-320)/160+1
+ * (1dnn_resynth/extractwav.cpp:67: one more frame, whose falling half covers the last hop). */
 int sea_resynth64_batch(const short *d_in, short *d_out, const long long *d_offsets,
                         const long long *d_lengths, const float *d_mask,
                         const long long *d_mask_offsets, float *d_inter, const int *d_order,

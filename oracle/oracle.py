@@ -124,12 +124,13 @@ class Oracle(_Lib):
         super().__init__(ORACLE_SO, "ora_")
         self.lib.ora_resynth64.restype = ctypes.c_int
 
-    def resynth64(self, x, mask, binary=False):
+    def resynth64(self, x, mask, binary=False, frames_l_over_160=False):
         x = np.ascontiguousarray(x, dtype=np.int16)
         mask = np.ascontiguousarray(mask, dtype=np.float32)
         out = np.zeros(x.size, np.int16)
+        mode = int(bool(binary)) | (2 if frames_l_over_160 else 0)
         rc = self.lib.ora_resynth64(_ptr(x), ctypes.c_long(x.size), _ptr(mask),
-                                    ctypes.c_int(mask.shape[0]), ctypes.c_int(int(binary)), _ptr(out))
+                                    ctypes.c_int(mask.shape[0]), ctypes.c_int(mode), _ptr(out))
         if rc:
             raise ValueError("ora_resynth64: bad L/F")
         return out

@@ -115,7 +115,12 @@ int ora_resynth64(const short *in, long L, const float *mask, int F, int binary,
     float *input, *g, *rev, *w, *acc;
     long n;
     int c, f;
-    if (L < WINDOW || F != (int)((L - WINDOW) / OFFSET + 1)) return 1;
+    /* binary: bit 0 = ideal-binary-mask variant; bit 1 = the older driver's frame count
+     * numFrame = L/160 (1dnn_resynth/extractwav.cpp:67; one more frame, whose falling half covers the
+     * last hop) instead of (L-320)/160+1 -- PARITY UNPINNED for that mode (no recorded output) */
+    const int alt = (binary >> 1) & 1;
+    binary &= 1;
+    if (alt ? (L < OFFSET || F != (int)(L / OFFSET)) : (L < WINDOW || F != (int)((L - WINDOW) / OFFSET + 1))) return 1;
     ora_resynth_channels(cf, bw, me);
     input = (float *)malloc(L * sizeof(float));
     g = (float *)malloc(L * sizeof(float));

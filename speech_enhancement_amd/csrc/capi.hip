@@ -492,8 +492,9 @@ int sea_resynth64_batch(const short *d_in, short *d_out, const long long *d_offs
 
 int sea_resynth64(const short *in, long L, const float *mask, int F, int binary, short *out)
 {
-    if (L < 320) return fail("resynth64: L=%ld is shorter than one 320-sample window", L);
-    if (F != (int)((L - 320) / 160 + 1)) return fail("resynth64: F=%d does not match L=%ld", F, L);
+    const long minL = (binary & 2) ? 160 : 320;
+    if (L < minL) return fail("resynth64: L=%ld is shorter than %ld samples", L, minL);
+    if (F != (int)((binary & 2) ? L / 160 : (L - 320) / 160 + 1)) return fail("resynth64: F=%d does not match L=%ld", F, L);
     const long long Lp = align8(L);
     DevBuf<short> din, dout;
     DevBuf<float> dmask, dinter;
@@ -522,18 +523,20 @@ int sea_resynth_utterances(const short *const *in, const long *lengths, const fl
     std::vector<long long> offs(n_utt), lens(n_utt), moffs(n_utt);
     long long total = 0, rows = 0;
     for (int u = 0; u < n_utt; ++u) {
-        if (lengths[u] < 320) return fail("resynth: utterance %d has %ld samples (< one 320-sample window)", u, lengths[u]);
+        if (lengths[u] < ((binary & 2) ? 160 : 320))
+            return fail("resynth: utterance %d has %ld samples (too short for one mask frame)", u, lengths[u]);
         offs[u] = total;
         lens[u] = lengths[u];
         moffs[u] = rows;
         total += align8(lengths[u]);
-        rows += (lengths[u] - 320) / 160 + 1;
+        rows += (binary & 2) ? lengths[u] / 160 : (lengths[u] - 320) / 160 + 1;
     }
     std::vector<short> pack((size_t)total, 0);
     std::vector<float> mpack((size_t)rows * 64);
     for (int u = 0; u < n_utt; ++u) {
         memcpy(&pack[(size_t)offs[u]], in[u], (size_t)lens[u] * sizeof(short));
-        memcpy(&mpack[(size_t)moffs[u] * 64], masks[u], (size_t)((lens[u] - 320) / 160 + 1) * 64 * sizeof(float));
+        memcpy(&mpack[(size_t)moffs[u] * 64], masks[u],
+               (size_t)((binary & 2) ? lens[u] / 160 : (lens[u] - 320) / 160 + 1) * 64 * sizeof(float));
     }
     DevBuf<short> din, dout;
     DevBuf<float> dmask, dinter;

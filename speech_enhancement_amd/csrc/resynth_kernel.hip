@@ -522,10 +522,11 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
         }
         RS_T_FLUSH(8);
     } else if (role == 2) {
-        const long long F = (L - 320) / 160 + 1;
+        /* mask rows: (L-320)/160+1, or L/160 with mode bit 1 (1dnn_resynth/extractwav.cpp:67) */
+        const long long F = (a.binary & 2) ? L / 160 : (L - 320) / 160 + 1;
         const float *mask = a.mask + a.mask_offsets[u] * 64 + lane;
         const DivConst ear = div_const(a.tables->midEar[lane]);
-        const bool binary = a.binary != 0;
+        const bool binary = (a.binary & 1) != 0;
         /* mask value of row h as the weight code sees it: the IBM variant turns > 0.5 into 1.0 and
          * skips everything else (resyth_64sub_IBM/cpp/extractwav.cpp:97-99); skipped == 0 here.
          * The load itself (mask_raw) is unconditional and one hop ahead of the interpretation
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long L = a.lengths[u];
-    if (L < 320) return; /* no mask frame fits (wave-uniform exit before any barrier) */
+    if (L < ((a.binary & 2) ? 160 : 320)) return; /* no mask frame fits (wave-uniform exit before any barrier) */
     resynth_bwd_body(a, S, role, lane, u, a.offsets[u], L);
 }
 
@@ -668,7 +669,7 @@ __global__ __launch_bounds__(256, 4) void resynth_fused_kernel(ResynthArgs a)
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long off = a.offsets[u], L = a.lengths[u];
-    if (L < 320) return;
+    if (L < ((a.binary & 2) ? 160 : 320)) return; /* no mask frame fits */
     resynth_fwd_body(a, S.f, role, lane, u, off, L);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_s_barrier();

@@ -57,13 +57,15 @@ def DoCompCeps(data201):
     return coef
 
 
-def resynth(x, mask, binary=False):
-    """resynth(): x int16[L], mask float32[F][64] with F=(L-320)/160+1 -> int16[L]."""
+def resynth(x, mask, binary=False, frames_l_over_160=False):
+    """resynth(): x int16[L], mask float32[F][64] with F=(L-320)/160+1 (or L/160 with
+    frames_l_over_160, the frame count of 1dnn_resynth/extractwav.cpp:67) -> int16[L]."""
     lib = _lib.load()
     x = np.ascontiguousarray(x, dtype=np.int16)
     mask = np.ascontiguousarray(mask, dtype=np.float32)
     out = np.zeros(x.size, np.int16)
-    rc = lib.sea_resynth64(_np_ptr(x), x.size, _np_ptr(mask), int(mask.shape[0]), int(bool(binary)), _np_ptr(out))
+    mode = int(bool(binary)) | (2 if frames_l_over_160 else 0)
+    rc = lib.sea_resynth64(_np_ptr(x), x.size, _np_ptr(mask), int(mask.shape[0]), mode, _np_ptr(out))
     _lib.check(rc, "resynth")
     return out
 
@@ -350,22 +352,22 @@ def resynth_scratch_elems(batch):
     return int(_lib.load().sea_resynth_scratch_bytes(int(batch.total), int(batch.n_utt))) // 4
 
 
-def resynth_batch(batch, masks, binary=False, out=None, scratch=None, use_order=True):
+def resynth_batch(batch, masks, binary=False, out=None, scratch=None, use_order=True, frames_l_over_160=False):
     """64-band gammatone resynthesis of every utterance of the batch (two launches on the current
     stream).  ``scratch`` (float32, resynth_scratch_elems(batch) elements) may be passed to reuse the HBM-resident
     analysis intermediate between calls."""
     torch = _torch()
     lib = _lib.load()
-    if np.any(np.asarray(batch.host_lengths) < 320):
-        raise ValueError("resynth needs utterances of at least 320 samples")
+    if np.any(np.asarray(batch.host_lengths) < (160 if frames_l_over_160 else 320)):
+        raise ValueError("resynth needs utterances of at least one mask frame")
     if out is None:
         out = torch.zeros_like(batch.data)
     if scratch is None:
         scratch = torch.empty(resynth_scratch_elems(batch), dtype=torch.float32, device=batch.data.device)
     rc = lib.sea_resynth64_batch(_dptr(batch.data), _dptr(out), _dptr(batch.offsets), _dptr(batch.lengths),
                                  _dptr(masks.data), _dptr(masks.row_offsets), _dptr(scratch),
-                                 _dptr(batch.order) if use_order else None, batch.n_utt, int(bool(binary)),
-                                 _stream_ptr())
+                                 _dptr(batch.order) if use_order else None, batch.n_utt,
+                                 int(bool(binary)) | (2 if frames_l_over_160 else 0), _stream_ptr())
     _lib.check(rc, "sea_resynth64_batch")
     return out, scratch
 
