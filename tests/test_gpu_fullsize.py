@@ -96,3 +96,28 @@ def test_resynth_1024_utterances(shard, oracle, binary):
     out0, _ = sea.resynth_batch(shard, zero, binary=binary, scratch=scratch)
     torch.cuda.synchronize()
     assert int(torch.count_nonzero(out0)) == 0
+
+
+def test_afe_feature_chain_1024_utterances(shard, oracle):
+    """SURVEY 8(f) #3 at configs[1] size: every utterance's emitted feature frames (c1..c12, c0, logE,
+    VAD flag) against the reference-pinned oracle -- exact VAD decisions, features within 1e-3."""
+    import speech_enhancement_amd as sea
+    res = sea.afe_features_batch(shard)
+    host = shard.data.cpu().numpy()
+    utts = [host[o:o + l] for o, l in zip(shard.host_offsets, shard.host_lengths)]
+
+    def ref(x):
+        return oracle.afe_trace(x)["vad_out"]
+    ref(utts[0][:1600])
+    with ThreadPoolExecutor(_threads()) as ex:
+        want = list(ex.map(ref, utts))
+    worst, frames, speech = 0.0, 0, 0
+    for u, (g, w) in enumerate(zip(res["feats"], want)):
+        assert g.shape == w.shape, f"utt {u}: {g.shape} vs {w.shape}"
+        assert np.array_equal(g[:, 14], w[:, 14]), f"utt {u}: VAD decisions differ"
+        worst = max(worst, float(np.abs(g[:, :14] - w[:, :14]).max()))
+        frames += len(g)
+        speech += int(g[:, 14].sum())
+    print(f"AFE chain: {frames} feature frames, {speech} flagged speech, worst |delta| = {worst}")
+    assert worst <= 1e-3
+    assert 0 < speech < frames
