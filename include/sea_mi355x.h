@@ -157,6 +157,14 @@ void sea_ns_stream_delete(sea_ns_stream *s);
 int sea_ns_streams_push(const float *d_in, float *d_out, int *d_produced, float *d_state, int n_streams,
                         int nframes, int reset, void *stream);
 int sea_ns_state_floats(void);
+/* the same, additionally reporting what the reference's batch plug-in shape hands back per frame
+ * (esti_denoise_out of function/20141106_speech_enhancement/aurora_etsi/NoiseSupExports.h:19-27, filled by
+ * etsi_denoise_mapping_func_Wiener): d_flags[stream][frame] bit 0 SpeechFoundVar, 1 Spec, 2 Mel,
+ * 3 VADNS; d_frame_counter[stream][frame] = FrameCounter after the tick.  In that API's terms:
+ * sea_init ~ ..._global_init, one state blob ~ ..._thread_init, one call ~ ..._func_Wiener on
+ * dataNum = 80*nframes samples (this engine implements the etsi/ arithmetic, 80-sample frames). */
+int sea_ns_streams_push_fd(const float *d_in, float *d_out, int *d_produced, unsigned char *d_flags,
+                           int *d_frame_counter, float *d_state, int n_streams, int nframes, int reset, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
  * device self-tests of the two places where a kernel takes a cheaper route than the reference's

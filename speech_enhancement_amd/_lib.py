@@ -46,6 +46,7 @@ PROTOTYPES = {
     "sea_ns_stream_push": (_i, [_vp, _vp, _vp]),
     "sea_ns_stream_delete": (None, [_vp]),
     "sea_ns_streams_push": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sea_ns_streams_push_fd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sea_ns_state_floats": (_i, []),
     "sea_selftest_pi4": (_i, [_vp]),
     "sea_selftest_div": (_i, [_vp]),

@@ -649,7 +649,7 @@ int sea_ns_stream_push(sea_ns_stream *s, const float *in80, float *out80)
         fprintf(stderr, "ERROR:   DoNoiseSup (MI355X): %s\r\n", s ? g_err : "NULL stream");
         exit(0); /* the reference's DoNoiseSup path ends the process on failure (NoiseSup.c:983-987) */
     }
-    sea::NsStreamArgs a;
+    sea::NsStreamArgs a = {};
     a.in = s->io;
     a.out = s->io + 80;
     a.produced = s->produced;
@@ -689,7 +689,7 @@ int sea_ns_streams_push(const float *d_in, float *d_out, int *d_produced, float 
     if (n_streams <= 0 || nframes <= 0) return 0;
     DeviceCtx *c;
     if (ctx(&c)) return 1;
-    sea::NsStreamArgs a;
+    sea::NsStreamArgs a = {};
     a.in = d_in;
     a.out = d_out;
     a.produced = d_produced;
@@ -698,6 +698,27 @@ int sea_ns_streams_push(const float *d_in, float *d_out, int *d_produced, float 
     a.nframes = nframes;
     a.reset = reset;
     hipLaunchKernelGGL(sea::ns_stream_kernel, dim3(n_streams), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sea_ns_streams_push_fd(const float *d_in, float *d_out, int *d_produced, unsigned char *d_flags,
+                           int *d_frame_counter, float *d_state, int n_streams, int nframes, int reset, void *stream)
+{
+    if (n_streams <= 0 || nframes <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    sea::NsStreamArgs a = {};
+    a.in = d_in;
+    a.out = d_out;
+    a.produced = d_produced;
+    a.state = d_state;
+    a.tables = c->ns;
+    a.nframes = nframes;
+    a.reset = reset;
+    a.flags = d_flags;
+    a.frame_counter = d_frame_counter;
+    hipLaunchKernelGGL(sea::ns_stream_fd_kernel, dim3(n_streams), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -586,11 +586,13 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
 
 /* One whole stage on the single-wave form: stage 0 deposits its 80 output samples in
  * ring[1][240..319], stage 1 in outb[0..79]. */
-template <int ST>
-__device__ __forceinline__ void ns_stage(NsLds &L, NsRegs &s, const NsConst &C, int lane)
+template <int ST, bool FD = false>
+__device__ __forceinline__ void ns_stage(NsLds &L, NsRegs &s, const NsConst &C, int lane, NsFd *fd = nullptr,
+                                         int *fdFlags = nullptr)
 {
     ns_front(L.ring[ST], L.work, L.psd, C.fft, C.win, lane);
-    ns_back<ST, false>(L.psd, L.ring[ST], L.back, s, C, (ST == 0) ? (L.ring[1] + 240) : L.outb, lane);
+    ns_back<ST, false, FD>(L.psd, L.ring[ST], L.back, s, C, (ST == 0) ? (L.ring[1] + 240) : L.outb, lane, 0.0f, nullptr,
+                           nullptr, fd, fdFlags);
 }
 
 /* DCOffsetFil over one frame (NoiseSup.c:182-198): y[n] = float( double(d[n]) + 0.9990234375 *
@@ -739,13 +741,15 @@ __device__ __forceinline__ bool dc_verify(const float *dif, float *out, float y0
 
 /* DoNoiseSup (NoiseSup.c:1061-1440) for one 80-sample frame.  Lanes 0..39 pass samples 2l and
  * 2l+1.  Returns true when L.outb[0..79] holds a DC-filtered output frame. */
-__device__ __forceinline__ bool ns_tick(NsLds &L, NsRegs &s, const NsConst &C, int lane, float x0, float x1)
+template <bool FD = false>
+__device__ __forceinline__ bool ns_tick(NsLds &L, NsRegs &s, const NsConst &C, int lane, float x0, float x1,
+                                        NsFd *fd = nullptr, int *fdFlags = nullptr)
 {
     if (lane < 40) *reinterpret_cast<float2 *>(&L.ring[0][240 + 2 * lane]) = make_float2(x0, x1);
     wave_sync();
     s.nIn1++;
     if (s.nIn1 - s.nIn2 > 2) { /* NoiseSup.c:1152 */
-        ns_stage<0>(L, s, C, lane);
+        ns_stage<0, FD>(L, s, C, lane, fd, fdFlags);
         s.nIn2++;
     }
     if (s.nIn2 - s.nOut2 > 2) { /* NoiseSup.c:1178 */
@@ -803,7 +807,8 @@ __device__ __forceinline__ void load_ns_const(NsConst &C, const sea_ns_tables *t
 /* ---- state blob of a stream (sea_ns_stream_*): [640 ring][12 x 64 per-lane][32 scalars] ---- */
 constexpr int kBlobLane = 2 * kRing, kBlobScal = kBlobLane + 12 * 64;
 
-__device__ __forceinline__ void state_store(float *blob, const NsLds &L, const NsRegs &s, int lane)
+__device__ __forceinline__ void state_store(float *blob, const NsLds &L, const NsRegs &s, int lane,
+                                            const NsFd *fd = nullptr, int fdBits = 0)
 {
     for (int i = lane; i < 2 * kRing; i += kLanes) blob[i] = (&L.ring[0][0])[i];
     float *p = blob + kBlobLane + lane;
@@ -821,12 +826,18 @@ __device__ __forceinline__ void state_store(float *blob, const NsLds &L, const N
         int *qi = reinterpret_cast<int *>(q + 16);
         q[0] = s.dcX; q[1] = s.dcY; q[2] = s.denEn0; q[3] = s.denEn1; q[4] = s.denEn2;
         q[5] = s.lowSNRtrack; q[6] = s.alfaGF; q[7] = s.meanEn;
+        if (fd) {
+            q[8] = fd->melMean; q[9] = fd->varMean; q[10] = fd->accTest; q[11] = fd->specMean;
+            q[12] = fd->mel0; q[13] = fd->specValues; q[14] = fd->speechInVADQ;
+            qi[9] = fdBits;
+        }
         qi[0] = s.nbFrame[0]; qi[1] = s.nbFrame[1]; qi[2] = s.flagVAD; qi[3] = s.hangOver;
         qi[4] = s.nbSpeech; qi[5] = s.nIn1; qi[6] = s.nIn2; qi[7] = s.nOut2; qi[8] = s.onset;
     }
 }
 
-__device__ __forceinline__ void state_load(const float *blob, NsLds &L, NsRegs &s, int lane)
+__device__ __forceinline__ void state_load(const float *blob, NsLds &L, NsRegs &s, int lane, NsFd *fd = nullptr,
+                                           int *fdBits = nullptr)
 {
     for (int i = lane; i < 2 * kRing; i += kLanes) (&L.ring[0][0])[i] = blob[i];
     const float *p = blob + kBlobLane + lane;
@@ -843,6 +854,11 @@ __device__ __forceinline__ void state_load(const float *blob, NsLds &L, NsRegs &
     const int *qi = reinterpret_cast<const int *>(q + 16);
     s.dcX = q[0]; s.dcY = q[1]; s.denEn0 = q[2]; s.denEn1 = q[3]; s.denEn2 = q[4];
     s.lowSNRtrack = q[5]; s.alfaGF = q[6]; s.meanEn = q[7];
+    if (fd) {
+        fd->melMean = q[8]; fd->varMean = q[9]; fd->accTest = q[10]; fd->specMean = q[11];
+        fd->mel0 = q[12]; fd->specValues = q[13]; fd->speechInVADQ = q[14];
+        if (fdBits) *fdBits = qi[9];
+    }
     s.nbFrame[0] = qi[0]; s.nbFrame[1] = qi[1]; s.flagVAD = qi[2]; s.hangOver = qi[3];
     s.nbSpeech = qi[4]; s.nIn1 = qi[5]; s.nIn2 = qi[6]; s.nOut2 = qi[7]; s.onset = qi[8];
 }

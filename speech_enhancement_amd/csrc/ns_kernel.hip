@@ -77,7 +77,10 @@ __global__ __launch_bounds__(64) void ns_denoise_kernel(NsBatchArgs a)
 
 /* DoNoiseSup-shaped streaming: state lives in HBM between calls (one blob per stream), frames are
  * float in / float out, no zero-frame gate (that belongs to DoAdvProcess, not DoNoiseSup). */
-__global__ __launch_bounds__(64) void ns_stream_kernel(NsStreamArgs a)
+namespace {
+
+template <bool FD>
+__device__ __forceinline__ void ns_stream_body(const NsStreamArgs &a)
 {
     __shared__ NsLds L;
     const int lane = threadIdx.x;
@@ -86,25 +89,42 @@ __global__ __launch_bounds__(64) void ns_stream_kernel(NsStreamArgs a)
     NsConst C;
     load_ns_const(C, a.tables, lane);
     NsRegs s;
+    NsFd fd;
+    fd_init(fd);
+    int bits = 0; /* the flags persist between ticks (and pushes) like FEParamsX's (ParmInterface.h:86-89) */
     if (a.reset) {
         regs_init(s, C.eps);
         for (int i = lane; i < 2 * kRing; i += kLanes) (&L.ring[0][0])[i] = 0.0f;
     } else
-        state_load(blob, L, s, lane);
+        state_load(blob, L, s, lane, FD ? &fd : nullptr, FD ? &bits : nullptr);
     wave_sync();
     for (int f = 0; f < a.nframes; ++f) {
         const float *x = a.in + ((long long)b * a.nframes + f) * SEA_HOP;
         float *y = a.out + ((long long)b * a.nframes + f) * SEA_HOP;
         float2 v = make_float2(0.0f, 0.0f);
         if (lane < 40) v = *reinterpret_cast<const float2 *>(x + 2 * lane);
-        const bool produced = ns_tick(L, s, C, lane, v.x, v.y);
+        const bool produced = ns_tick<FD>(L, s, C, lane, v.x, v.y, &fd, &bits);
         if (produced && lane < 40)
             *reinterpret_cast<float2 *>(y + 2 * lane) = *reinterpret_cast<const float2 *>(&L.outb[2 * lane]);
-        if (lane == 0) a.produced[(long long)b * a.nframes + f] = produced ? 1 : 0;
+        if (lane == 0) {
+            a.produced[(long long)b * a.nframes + f] = produced ? 1 : 0;
+            if (FD) {
+                if (a.flags) a.flags[(long long)b * a.nframes + f] = (unsigned char)bits;
+                if (a.frame_counter) a.frame_counter[(long long)b * a.nframes + f] = s.nbFrame[0];
+            }
+        }
         wave_sync();
     }
-    state_store(blob, L, s, lane);
+    state_store(blob, L, s, lane, FD ? &fd : nullptr, bits);
 }
+
+} // namespace
+
+__global__ __launch_bounds__(64) void ns_stream_kernel(NsStreamArgs a) { ns_stream_body<false>(a); }
+
+/* the same with the frame-dropping VAD's inputs (the etsi_denoise_mapping_func_Wiener output shape:
+ * function/20141106_speech_enhancement/aurora_etsi/NoiseSupExports.h:19-27) */
+__global__ __launch_bounds__(64) void ns_stream_fd_kernel(NsStreamArgs a) { ns_stream_body<true>(a); }
 
 /* ---- device self-tests behind sea_selftest_*(): exhaustive / adversarial checks of the two places
  * where the kernel takes a cheaper route than the reference's literal arithmetic ---- */

@@ -37,6 +37,8 @@ struct NsStreamArgs {
     const sea_ns_tables *tables;
     int nframes;
     int reset;                 /* 1: start from DoNoiseSupInit state instead of loading */
+    unsigned char *flags;      /* optional [B][nframes]: bit 0 SpeechFoundVar, 1 Spec, 2 Mel, 3 VADNS of the tick */
+    int *frame_counter;        /* optional [B][nframes]: FEParamsX::FrameCounter after the tick */
 };
 
 struct CepsArgs {
@@ -101,6 +103,7 @@ __global__ void ns_denoise_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_fd_kernel(NsBatchArgs a); /* + speech flags for the frame-dropping VAD */
 __global__ void ns_stream_kernel(NsStreamArgs a);
+__global__ void ns_stream_fd_kernel(NsStreamArgs a);
 __global__ void selftest_pi4_kernel(unsigned long long *mismatches);
 __global__ void selftest_dc_kernel(const float *dif, const float *y0, float *out, int *fellback, int ncases);
 __global__ void selftest_log_kernel(const float *x, double *out, int n);

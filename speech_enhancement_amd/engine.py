@@ -385,9 +385,11 @@ def subband_batch(batch, out=None, use_order=True):
     return out
 
 
-def ns_streams_push(frames, state=None, reset=None):
+def ns_streams_push(frames, state=None, reset=None, want_flags=False):
     """Batched DoNoiseSup: frames float32 [B, nframes, 80] on the GPU.  Returns (out, produced, state);
-    pass ``state`` back in to continue the same streams."""
+    pass ``state`` back in to continue the same streams.  want_flags: also return (flags uint8
+    [B, nframes] with bit 0 SpeechFoundVar, 1 Spec, 2 Mel, 3 VADNS, frame_counter int32 [B, nframes]),
+    the per-frame outputs of the reference's batch plug-in shape (NoiseSupExports.h:19-27)."""
     torch = _torch()
     lib = _lib.load()
     frames = frames.contiguous()
@@ -398,6 +400,13 @@ def ns_streams_push(frames, state=None, reset=None):
         reset = True if reset is None else reset
     out = torch.zeros_like(frames)
     produced = torch.zeros((B, nfr), dtype=torch.int32, device=frames.device)
+    if want_flags:
+        flags = torch.zeros((B, nfr), dtype=torch.uint8, device=frames.device)
+        counter = torch.zeros((B, nfr), dtype=torch.int32, device=frames.device)
+        rc = lib.sea_ns_streams_push_fd(_dptr(frames), _dptr(out), _dptr(produced), _dptr(flags), _dptr(counter),
+                                        _dptr(state), B, nfr, int(bool(reset)), _stream_ptr())
+        _lib.check(rc, "sea_ns_streams_push_fd")
+        return out, produced, state, flags, counter
     rc = lib.sea_ns_streams_push(_dptr(frames), _dptr(out), _dptr(produced), _dptr(state), B, nfr,
                                  int(bool(reset)), _stream_ptr())
     _lib.check(rc, "sea_ns_streams_push")

@@ -524,3 +524,26 @@ def test_resynth_l_over_160_frame_count(oracle, binary):
         assert np.array_equal(y, want), f"utt {u} (L={len(x)})"
     one = sea.resynth(utts[0], masks[0], binary=binary, frames_l_over_160=True)
     assert np.array_equal(one, oracle.resynth64(utts[0], masks[0], binary=binary, frames_l_over_160=True))
+
+
+def test_ns_stream_plugin_flags_vs_oracle(oracle):
+    """The streaming plug-in with the per-frame outputs of the reference's batch plug-in shape
+    (SpeechFoundVar/Spec/Mel/VADNS + FrameCounter, NoiseSupExports.h:19-27), pushed in two calls so that
+    the frame-dropping state crosses a state-blob save / load."""
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    torch = _torch()
+    x = corpus.synth_utterance(21, 80 * 120)          # no leading zero frames: the stream never gates
+    tr = oracle.afe_trace(x)
+    ns = oracle.ns_trace(x, want_state=False)
+    frames = torch.from_numpy(x.astype(np.float32).reshape(1, -1, 80)).cuda().repeat(2, 1, 1)
+    o1, p1, st, f1, c1 = sea.ns_streams_push(frames[:, :37].contiguous(), want_flags=True)
+    o2, p2, st, f2, c2 = sea.ns_streams_push(frames[:, 37:].contiguous(), state=st, reset=False, want_flags=True)
+    flags = torch.cat([f1, f2], 1).cpu().numpy()
+    counter = torch.cat([c1, c2], 1).cpu().numpy()
+    out = torch.cat([o1, o2], 1).cpu().numpy()
+    want_flags = tr["flags"][:, :4] @ np.array([1, 2, 4, 8])
+    for b in range(2):
+        assert np.array_equal(flags[b], want_flags), np.nonzero(flags[b] != want_flags)[0][:5]
+        assert np.array_equal(counter[b], tr["flags"][:, 4])
+        assert np.array_equal(out[b, 4:].reshape(-1).view(np.uint32), ns["den_f32"].view(np.uint32))
