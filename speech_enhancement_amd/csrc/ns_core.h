@@ -384,6 +384,21 @@ __device__ __forceinline__ void psd_from_fft(const float *work, float *psd, int 
     }
 }
 
+/* the same on the swizzled work area of the dual transform (addresses from the tables) */
+__device__ __forceinline__ void psd_from_fft2(const float *work, float *psd, const Fft2Regs &R, int lane)
+{
+    const float re0 = fft_at(work, R.psdA[0] & 0xffffu), re1 = fft_at(work, R.psdA[0] >> 16);
+    const float im1 = fft_at(work, R.psdA[1] & 0xffffu);
+    const float im0 = (lane > 0) ? fft_at(work, R.psdA[1] >> 16) : 0.0f;
+    const float p0 = (lane > 0) ? (re0 * re0 + im0 * im0) : (re0 * re0);
+    const float p1 = re1 * re1 + im1 * im1;
+    psd[lane] = (p0 + p1) * 0.5f;
+    if (lane == 0) {
+        const float ny = fft_at(work, R.nyq);
+        psd[64] = ny * ny;
+    }
+}
+
 /* Two FRONT halves in one wave: frame A (stage buffer bufA) and frame B (bufB) are windowed,
  * transformed side by side (rfft256_dual) and reduced to their 65-bin PSDs.  actA / actB are
  * wave-uniform; an inactive side is fed zeros and its PSD is not written.  work: 512 floats. */
@@ -400,8 +415,8 @@ __device__ __forceinline__ void ns_front_dual(const float *bufA, bool actA, floa
         eB[k] = (actB && in) ? bufB[idx] * win[k] : 0.0f;
     }
     rfft256_dual(eA, eB, work, fft, flags, lane);
-    if (actA) psd_from_fft(work, psdA, lane);
-    if (actB) psd_from_fft(work + 256, psdB, lane);
+    if (actA) psd_from_fft2(work, psdA, fft, lane);
+    if (actB) psd_from_fft2(work + 256, psdB, fft, lane);
     wave_sync();
 }
 

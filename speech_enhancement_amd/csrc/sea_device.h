@@ -168,33 +168,54 @@ __device__ __forceinline__ void rfft256(float e0, float e1, float e2, float e3, 
  * (SEA_BF_PAIR) so that no level needs more than 32 lanes per transform.  work holds the two
  * frames back to back: transform A in work[0..255], B in work[256..511]. */
 struct Fft2Regs {
-    unsigned item[SEA_FFT_LSTAGES]; /* kind<<24 | b<<12 | a, a/b already offset by 256 for lanes >= 32 */
+    unsigned kind[SEA_FFT_LSTAGES];
+    unsigned addr[SEA_FFT_LSTAGES][4]; /* byte offsets of the eight operands, two per word, already moved
+                                        * into the second work area for lanes >= 32 (sea_tables.h) */
     float tw[SEA_FFT_LSTAGES][4];
+    unsigned headA[2], psdA[2];        /* frame A: where this lane stores its head values / finds its PSD inputs */
+    unsigned nyq;
 };
+
+/* LDS word at byte offset `off` of the work area */
+__device__ __forceinline__ float &fft_at(float *work, unsigned off)
+{
+    return *reinterpret_cast<float *>(reinterpret_cast<char *>(work) + off);
+}
+__device__ __forceinline__ const float &fft_at(const float *work, unsigned off)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(work) + off);
+}
 
 __device__ __forceinline__ void load_fft2_regs(Fft2Regs &R, const sea_fft_tables *t, int lane)
 {
     const int j = lane & 31;
-    const unsigned half = (lane >> 5) * 256u;
+    const unsigned half = (unsigned)(lane >> 5) * 1024u; /* second transform: the next 256 words */
+    const unsigned both = half | (half << 16);
 #pragma unroll
     for (int s = 0; s < SEA_FFT_LSTAGES; ++s) {
-        const unsigned it = t->fft2Item[s][j];
-        const unsigned kind = it >> 16, a = (it & 255u) + half, b = ((it >> 8) & 255u) + half;
-        R.item[s] = (kind << 24) | (b << 12) | a;
+        R.kind[s] = t->fft2Item[s][j] >> 16;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) R.tw[s][k] = t->fft2Tw[s][k][j];
+        for (int k = 0; k < 4; ++k) {
+            R.addr[s][k] = t->fft2Addr[s][k][j] + both;
+            R.tw[s][k] = t->fft2Tw[s][k][j];
+        }
     }
+    R.headA[0] = t->fft2Head[0][lane];
+    R.headA[1] = t->fft2Head[1][lane];
+    R.psdA[0] = t->fft2Psd[0][lane];
+    R.psdA[1] = t->fft2Psd[1][lane];
+    R.nyq = t->fft2Nyq;
 }
 
 template <int S>
 __device__ __forceinline__ void fft2_level(float *work, const Fft2Regs &R)
 {
-    constexpr int n4 = 2 << S;
-    const unsigned it = R.item[S];
-    const unsigned kind = it >> 24;
-    const int a = (int)(it & 4095u), b = (int)((it >> 12) & 4095u);
-    const float x1 = work[a], x2 = work[a + n4], x3 = work[a + 2 * n4], x4 = work[a + 3 * n4];
-    const float x5 = work[b], x6 = work[b + n4], x7 = work[b + 2 * n4], x8 = work[b + 3 * n4];
+    const unsigned kind = R.kind[S];
+    const unsigned a01 = R.addr[S][0], a23 = R.addr[S][1], b01 = R.addr[S][2], b23 = R.addr[S][3];
+    const float x1 = fft_at(work, a01 & 0xffffu), x2 = fft_at(work, a01 >> 16);
+    const float x3 = fft_at(work, a23 & 0xffffu), x4 = fft_at(work, a23 >> 16);
+    const float x5 = fft_at(work, b01 & 0xffffu), x6 = fft_at(work, b01 >> 16);
+    const float x7 = fft_at(work, b23 & 0xffffu), x8 = fft_at(work, b23 >> 16);
     float o1, o2, o3, o4, o5, o6, o7, o8;
     if (kind == SEA_BF_TWIDDLE) { /* rfft.c:145-174 */
         const float cc1 = R.tw[S][0], ss1 = R.tw[S][1], cc3 = R.tw[S][2], ss3 = R.tw[S][3];
@@ -228,21 +249,21 @@ __device__ __forceinline__ void fft2_level(float *work, const Fft2Regs &R)
         o5 = x5 + u2;
     }
     if (kind != SEA_BF_NONE) {
-        work[a] = o1;
-        work[a + n4] = o2;
-        work[a + 2 * n4] = o3;
-        work[a + 3 * n4] = o4;
-        work[b] = o5;
-        work[b + n4] = o6;
-        work[b + 2 * n4] = o7;
-        work[b + 3 * n4] = o8;
+        fft_at(work, a01 & 0xffffu) = o1;
+        fft_at(work, a01 >> 16) = o2;
+        fft_at(work, a23 & 0xffffu) = o3;
+        fft_at(work, a23 >> 16) = o4;
+        fft_at(work, b01 & 0xffffu) = o5;
+        fft_at(work, b01 >> 16) = o6;
+        fft_at(work, b23 & 0xffffu) = o7;
+        fft_at(work, b23 >> 16) = o8;
     }
 }
 
 /* the register-resident start of rfft256 (bit reversal, length-2 and n2=4 butterflies) for one
- * frame; stores the lane's four values at work[4r..4r+3] */
+ * frame; stores the lane's four values at the (swizzled) places of elements 4r..4r+3, r = bitrev6(lane) */
 __device__ __forceinline__ void rfft256_head(float e0, float e1, float e2, float e3, float *work,
-                                             unsigned flags, int lane)
+                                             unsigned flags, const unsigned (&head)[2])
 {
     float g0 = e0, g1 = e2, g2 = e1, g3 = e3;
     {
@@ -261,8 +282,10 @@ __device__ __forceinline__ void rfft256_head(float e0, float e1, float e2, float
         g2 = f ? n2 : g2;
         g0 = f ? n0 : g0;
     }
-    const int r = (int)(__brev((unsigned)lane) >> 26);
-    *reinterpret_cast<float4 *>(work + 4 * r) = make_float4(g0, g1, g2, g3);
+    fft_at(work, head[0] & 0xffffu) = g0;
+    fft_at(work, head[0] >> 16) = g1;
+    fft_at(work, head[1] & 0xffffu) = g2;
+    fft_at(work, head[1] >> 16) = g3;
 }
 
 /* two transforms at once: eA / eB hold the lane's four (windowed) elements of frame A / B.
@@ -272,8 +295,8 @@ __device__ __forceinline__ void rfft256_head(float e0, float e1, float e2, float
 __device__ __forceinline__ void rfft256_dual_lo(const float (&eA)[4], const float (&eB)[4], float *work,
                                                 const Fft2Regs &R, unsigned flags, int lane)
 {
-    rfft256_head(eA[0], eA[1], eA[2], eA[3], work, flags, lane);
-    rfft256_head(eB[0], eB[1], eB[2], eB[3], work + 256, flags, lane);
+    rfft256_head(eA[0], eA[1], eA[2], eA[3], work, flags, R.headA);
+    rfft256_head(eB[0], eB[1], eB[2], eB[3], work + 256, flags, R.headA);
     wave_sync();
     fft2_level<0>(work, R);
     wave_sync();

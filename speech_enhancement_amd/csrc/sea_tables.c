@@ -120,7 +120,26 @@ static void build_fft(sea_fft_tables *f)
             if (slot >= 32) abort();
             f->fft2Item[s][slot] = ((unsigned)SEA_BF_PAIR << 16) | (ip << 8) | i1;
         }
+        /* swizzled byte addresses of the eight operands of every half-wave item (idle slots: item 0 ->
+         * element 0, fetched and ignored) */
+        for (j = 0; j < 32; j++) {
+            unsigned it = f->fft2Item[s][j], a = it & 255u, bb = (it >> 8) & 255u, k;
+            for (k = 0; k < 4; k++) {
+                unsigned e0 = (k < 2 ? a : bb) + (unsigned)((2 * k) & 3) * (unsigned)n4;
+                unsigned e1 = (k < 2 ? a : bb) + (unsigned)((2 * k + 1) & 3) * (unsigned)n4;
+                if (e0 > 255u || e1 > 255u) abort();
+                f->fft2Addr[s][k][j] = (sea_fft_swizzle(e0) * 4u) | ((sea_fft_swizzle(e1) * 4u) << 16);
+            }
+        }
     }
+    for (lane = 0; lane < SEA_LANES; lane++) {
+        unsigned g = 4u * bitrev((unsigned)lane, 6), l = (unsigned)lane;
+        f->fft2Head[0][lane] = (sea_fft_swizzle(g) * 4u) | ((sea_fft_swizzle(g + 1) * 4u) << 16);
+        f->fft2Head[1][lane] = (sea_fft_swizzle(g + 2) * 4u) | ((sea_fft_swizzle(g + 3) * 4u) << 16);
+        f->fft2Psd[0][lane] = (sea_fft_swizzle(2 * l) * 4u) | ((sea_fft_swizzle(2 * l + 1) * 4u) << 16);
+        f->fft2Psd[1][lane] = (sea_fft_swizzle(255 - 2 * l) * 4u) | ((sea_fft_swizzle((256 - 2 * l) & 255u) * 4u) << 16);
+    }
+    f->fft2Nyq = sea_fft_swizzle(128) * 4u;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -45,7 +45,30 @@ typedef struct {
      * brings every level to at most 32 items. */
     unsigned fft2Item[SEA_FFT_LSTAGES][32];
     float fft2Tw[SEA_FFT_LSTAGES][4][32];
+    /* LDS placement of the half-wave schedule.  Element i of a frame lives at word
+     * sea_fft_swizzle(i) = i ^ kSwz[i >> 5] of its 256-word work area: with the natural layout the 32
+     * lanes of a level hit 2..8 LDS banks (items sit 16, 32, ... words apart: 208 bank passes for
+     * the 48 operand reads of a transform); with this XOR per 32-word block they hit 50.  All
+     * addresses are table-driven, as BYTE offsets packed two per word (low | high << 16):
+     *   fft2Addr[s][k][j]  operands 2k, 2k+1 of item j at level s, in the order
+     *                      a, a+n4, a+2n4, a+3n4, b, b+n4, b+2n4, b+3n4
+     *   fft2Head[k][l]     where lane l stores its bit-reversed head values 2k, 2k+1
+     *   fft2Psd[k][l]      where lane l finds Re(2l), Re(2l+1) (k=0) and Im(2l+1) = x[255-2l],
+     *                      Im(2l) = x[256-2l] (k=1; lane 0's second entry is unused)
+     *   fft2Nyq            byte offset of x[128] */
+    unsigned fft2Addr[SEA_FFT_LSTAGES][4][32];
+    unsigned fft2Head[2][SEA_LANES];
+    unsigned fft2Psd[2][SEA_LANES];
+    unsigned fft2Nyq;
+    unsigned fft2Pad[3];
 } sea_fft_tables;
+
+/* word index of element i (0..255) in the swizzled work area */
+static inline unsigned sea_fft_swizzle(unsigned i)
+{
+    static const unsigned char kSwz[8] = {0, 6, 29, 15, 18, 20, 9, 27};
+    return i ^ kSwz[(i >> 5) & 7];
+}
 
 enum { SEA_BF_PAIR = 4 };
 
