@@ -20,12 +20,16 @@ __global__ __launch_bounds__(64) void rfft256_kernel(const float *in, float *out
 {
     __shared__ __attribute__((aligned(16))) float work[256];
     const int lane = threadIdx.x;
-    FftRegs R;
+    FftRegsSwz R; /* swizzled work area: no LDS bank conflicts in the butterflies */
     load_fft_regs(R, t, lane);
     for (long long f = blockIdx.x; f < nframes; f += gridDim.x) {
         const float *x = in + f * 256;
         rfft256(x[lane], x[lane + 64], x[lane + 128], x[lane + 192], work, R, lane);
-        const float4 v = *reinterpret_cast<const float4 *>(work + 4 * lane);
+        float4 v; /* elements 4l..4l+3 of the reference's order, wherever the swizzle put them */
+        v.x = fft_at(work, fft_swz(4u * lane + 0u));
+        v.y = fft_at(work, fft_swz(4u * lane + 1u));
+        v.z = fft_at(work, fft_swz(4u * lane + 2u));
+        v.w = fft_at(work, fft_swz(4u * lane + 3u));
         *reinterpret_cast<float4 *>(out + f * 256 + 4 * lane) = v;
         wave_sync();
     }

@@ -369,22 +369,8 @@ __device__ __forceinline__ void ns_front(const float *buf, float *work, float *p
     wave_sync();
 }
 
-/* FFTtoPSD (NoiseSup.c:249-270) of one transformed frame in work[0..255] -> psd[0..64] */
-__device__ __forceinline__ void psd_from_fft(const float *work, float *psd, int lane)
-{
-    const float re0 = work[2 * lane], re1 = work[2 * lane + 1];
-    const float im1 = work[255 - 2 * lane];
-    const float im0 = (lane > 0) ? work[256 - 2 * lane] : 0.0f;
-    const float p0 = (lane > 0) ? (re0 * re0 + im0 * im0) : (re0 * re0);
-    const float p1 = re1 * re1 + im1 * im1;
-    psd[lane] = (p0 + p1) * 0.5f;
-    if (lane == 0) {
-        const float ny = work[128];
-        psd[64] = ny * ny;
-    }
-}
-
-/* the same on the swizzled work area of the dual transform (addresses from the tables) */
+/* FFTtoPSD (NoiseSup.c:249-270) of one transformed frame of the dual transform -> psd[0..64]
+ * (addresses from the tables: the work area is swizzled) */
 __device__ __forceinline__ void psd_from_fft2(const float *work, float *psd, const Fft2Regs &R, int lane)
 {
     const float re0 = fft_at(work, R.psdA[0] & 0xffffu), re1 = fft_at(work, R.psdA[0] >> 16);

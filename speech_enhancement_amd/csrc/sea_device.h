@@ -30,6 +30,7 @@ __device__ __forceinline__ void wave_sync()
 }
 
 /* per-lane constants of the FFT schedule (sea_fft_tables), loaded once, kept in VGPRs */
+/* per-lane constants of the FFT schedule (sea_fft_tables), loaded once, kept in VGPRs */
 struct FftRegs {
     unsigned flags;
     unsigned item[SEA_FFT_LSTAGES];
@@ -111,6 +112,114 @@ __device__ __forceinline__ void fft_level(float *work, const FftRegs &R)
     }
 }
 
+/* The FFT work area in LDS is XOR-swizzled per 32-word block (sea_tables.h::sea_fft_swizzle): with the
+ * natural layout the lanes of a level hit 2..8 banks.  Butterfly operands, head stores and PSD reads
+ * take their (byte) addresses from tables; the few other readers call fft_swz(). */
+__device__ __forceinline__ unsigned fft_swz(unsigned i) /* element index -> BYTE offset in the work area */
+{
+    constexpr unsigned long long kSwz = 0ull | (6ull << 5) | (29ull << 10) | (15ull << 15) | (18ull << 20) | (20ull << 25) |
+                                        (9ull << 30) | (27ull << 35); /* {0, 6, 29, 15, 18, 20, 9, 27} */
+    return (i ^ (unsigned)((kSwz >> (5u * ((i >> 5) & 7u))) & 31ull)) * 4u;
+}
+__device__ __forceinline__ float &fft_at(float *work, unsigned off)
+{
+    return *reinterpret_cast<float *>(reinterpret_cast<char *>(work) + off);
+}
+__device__ __forceinline__ const float &fft_at(const float *work, unsigned off)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(work) + off);
+}
+
+struct FftRegsSwz {
+    unsigned flags;
+    unsigned kind[SEA_FFT_LSTAGES];
+    unsigned addr[SEA_FFT_LSTAGES][4]; /* byte offsets of the eight operands, two per word (sea_tables.h) */
+    float tw[SEA_FFT_LSTAGES][4];
+    unsigned head[2], psd[2], nyq;     /* where this lane stores its head values / finds its PSD inputs */
+};
+
+__device__ __forceinline__ void load_fft_regs(FftRegsSwz &R, const sea_fft_tables *t, int lane)
+{
+    R.flags = t->fftFlags[lane];
+#pragma unroll
+    for (int s = 0; s < SEA_FFT_LSTAGES; ++s) {
+        R.kind[s] = t->fftItem[s][lane] >> 16;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            R.addr[s][k] = t->fftAddr[s][k][lane];
+            R.tw[s][k] = t->fftTw[s][k][lane];
+        }
+    }
+    R.head[0] = t->fft2Head[0][lane];
+    R.head[1] = t->fft2Head[1][lane];
+    R.psd[0] = t->fft2Psd[0][lane];
+    R.psd[1] = t->fft2Psd[1][lane];
+    R.nyq = t->fft2Nyq;
+}
+
+/* The same level on the swizzled work area (table-driven addresses).
+ * Arithmetic: etsi/cpp/rfft.c:110-113 (plain), :120-125 (pi/4), :145-174 (twiddled). */
+template <int S>
+__device__ __forceinline__ void fft_level(float *work, const FftRegsSwz &R)
+{
+    const unsigned kind = R.kind[S];
+    const unsigned a01 = R.addr[S][0], a23 = R.addr[S][1], b01 = R.addr[S][2], b23 = R.addr[S][3];
+    /* All operands are fetched before the (divergent) arithmetic so that the three butterfly kinds
+     * share ONE LDS round trip instead of paying one each. */
+    const float x1 = fft_at(work, a01 & 0xffffu), x2 = fft_at(work, a01 >> 16);
+    const float x3 = fft_at(work, a23 & 0xffffu), x4 = fft_at(work, a23 >> 16);
+    const float x5 = fft_at(work, b01 & 0xffffu), x6 = fft_at(work, b01 >> 16);
+    const float x7 = fft_at(work, b23 & 0xffffu), x8 = fft_at(work, b23 >> 16);
+    float o1 = x1, o2 = x2, o3 = x3, o4 = x4, o5 = x5, o6 = x6, o7 = x7, o8 = x8;
+    if (kind == SEA_BF_TWIDDLE) {
+        const float cc1 = R.tw[S][0], ss1 = R.tw[S][1], cc3 = R.tw[S][2], ss3 = R.tw[S][3];
+        float t1 = x3 * cc1 + x7 * ss1;
+        float t2 = x7 * cc1 - x3 * ss1;
+        float t3 = x4 * cc3 + x8 * ss3;
+        float t4 = x8 * cc3 - x4 * ss3;
+        const float t5 = t1 + t3, t6 = t2 + t4;
+        t3 = t1 - t3;
+        t4 = t2 - t4;
+        o3 = t6 - x6;  /* x[i3] */
+        o8 = x6 + t6;  /* x[i8] */
+        o7 = -x2 - t3; /* x[i7] */
+        o4 = x2 - t3;  /* x[i4] */
+        o6 = x1 - t5;  /* x[i6] */
+        o1 = x1 + t5;  /* x[i1] */
+        o5 = x5 - t4;  /* x[i5] */
+        o2 = x5 + t4;  /* x[i2] */
+    } else if (kind == SEA_BF_PLAIN) {
+        const float t1 = x4 + x3;
+        o4 = x4 - x3;
+        o3 = x1 - t1;
+        o1 = x1 + t1;
+    } else if (kind == SEA_BF_PI4) {
+        /* Reference: float sum, DOUBLE division by M_SQRT2, rounded back to float (rfft.c:120-121).
+         * (float)((double)s * (1/sqrt2)) gives the same float for EVERY float s: both doubles are
+         * within 2^-52 (relative) of s/sqrt2, and s/sqrt2 can never be that close to a float
+         * rounding boundary, because |sqrt2*m - (2k+1)| > 1/(2.83 m) for integers m < 2^24 keeps it
+         * 2^-50.6 away.  tests/test_gpu_parity.py checks all 2^32 floats on the device. */
+        const float t1 = (float)((double)(x3 + x4) * 0.70710678118654752440);
+        const float t2 = (float)((double)(x3 - x4) * 0.70710678118654752440);
+        o4 = x2 - t1;
+        o3 = -x2 - t1;
+        o2 = x1 - t2;
+        o1 = x1 + t2;
+    }
+    if (kind != SEA_BF_NONE) {
+        fft_at(work, a01 & 0xffffu) = o1;
+        fft_at(work, a01 >> 16) = o2;
+        fft_at(work, a23 & 0xffffu) = o3;
+        fft_at(work, a23 >> 16) = o4;
+    }
+    if (kind == SEA_BF_TWIDDLE) {
+        fft_at(work, b01 & 0xffffu) = o5;
+        fft_at(work, b01 >> 16) = o6;
+        fft_at(work, b23 & 0xffffu) = o7;
+        fft_at(work, b23 >> 16) = o8;
+    }
+}
+
 /* exhaustive check kernel for the pi/4 identity above: counts floats s for which
  * (float)((double)s * inv_sqrt2) != (float)((double)s / sqrt2) */
 __device__ __forceinline__ bool pi4_identity_holds(float s)
@@ -163,6 +272,52 @@ __device__ __forceinline__ void rfft256(float e0, float e1, float e2, float e3, 
 #endif
 }
 
+/* Swizzled form of rfft256: 256-point real split-radix FFT of one frame held 4 elements per lane: lane l passes elements
+ * l, l+64, l+128, l+192 (already windowed / zero padded).  Result: element i of the reference's order
+ * Re(0..128), Im(127..1) (etsi/cpp/rfft.c:27-29) sits at byte offset fft_swz(i) of work.  Ends with a
+ * wave_sync(). */
+__device__ __forceinline__ void rfft256(float e0, float e1, float e2, float e3, float *work,
+                                        const FftRegsSwz &R, int lane)
+{
+    /* bit reversal: positions 4r..4r+3 (r = bitrev6(lane)) take elements l, l+128, l+64, l+192 */
+    float g0 = e0, g1 = e2, g2 = e1, g3 = e3;
+    {   /* length-two butterflies (rfft.c:82-96) */
+        const float s01 = g0 + g1, d01 = g0 - g1, s23 = g2 + g3, d23 = g2 - g3;
+        const bool f0 = (R.flags & 1u) != 0, f1 = (R.flags & 2u) != 0;
+        g0 = f0 ? s01 : g0;
+        g1 = f0 ? d01 : g1;
+        g2 = f1 ? s23 : g2;
+        g3 = f1 ? d23 : g3;
+    }
+    {   /* n2 = 4 level: plain butterfly only (rfft.c:110-113) */
+        const float t1 = g3 + g2;
+        const float n3 = g3 - g2, n2 = g0 - t1, n0 = g0 + t1;
+        const bool f = (R.flags & 4u) != 0;
+        g3 = f ? n3 : g3;
+        g2 = f ? n2 : g2;
+        g0 = f ? n0 : g0;
+    }
+    fft_at(work, R.head[0] & 0xffffu) = g0;
+    fft_at(work, R.head[0] >> 16) = g1;
+    fft_at(work, R.head[1] & 0xffffu) = g2;
+    fft_at(work, R.head[1] >> 16) = g3;
+    wave_sync();
+#ifndef SEA_ABLATE_FFT
+    fft_level<0>(work, R);
+    wave_sync();
+    fft_level<1>(work, R);
+    wave_sync();
+    fft_level<2>(work, R);
+    wave_sync();
+    fft_level<3>(work, R);
+    wave_sync();
+    fft_level<4>(work, R);
+    wave_sync();
+    fft_level<5>(work, R);
+    wave_sync();
+#endif
+}
+
 /* ---- two independent 256-point transforms side by side in one wave (lanes 0..31 / 32..63) ----
  * Same butterflies, same arithmetic; the plain and pi/4 butterflies of a block share one work item
  * (SEA_BF_PAIR) so that no level needs more than 32 lanes per transform.  work holds the two
@@ -176,15 +331,6 @@ struct Fft2Regs {
     unsigned nyq;
 };
 
-/* LDS word at byte offset `off` of the work area */
-__device__ __forceinline__ float &fft_at(float *work, unsigned off)
-{
-    return *reinterpret_cast<float *>(reinterpret_cast<char *>(work) + off);
-}
-__device__ __forceinline__ const float &fft_at(const float *work, unsigned off)
-{
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(work) + off);
-}
 
 __device__ __forceinline__ void load_fft2_regs(Fft2Regs &R, const sea_fft_tables *t, int lane)
 {

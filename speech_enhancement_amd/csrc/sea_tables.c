@@ -120,6 +120,16 @@ static void build_fft(sea_fft_tables *f)
             if (slot >= 32) abort();
             f->fft2Item[s][slot] = ((unsigned)SEA_BF_PAIR << 16) | (ip << 8) | i1;
         }
+        /* swizzled byte addresses of the eight operands of every full-wave item */
+        for (j = 0; j < SEA_LANES; j++) {
+            unsigned it = f->fftItem[s][j], a = it & 255u, bb = (it >> 8) & 255u, k;
+            for (k = 0; k < 4; k++) {
+                unsigned e0 = (k < 2 ? a : bb) + (unsigned)((2 * k) & 3) * (unsigned)n4;
+                unsigned e1 = (k < 2 ? a : bb) + (unsigned)((2 * k + 1) & 3) * (unsigned)n4;
+                if (e0 > 255u || e1 > 255u) abort();
+                f->fftAddr[s][k][j] = (sea_fft_swizzle(e0) * 4u) | ((sea_fft_swizzle(e1) * 4u) << 16);
+            }
+        }
         /* swizzled byte addresses of the eight operands of every half-wave item (idle slots: item 0 ->
          * element 0, fetched and ignored) */
         for (j = 0; j < 32; j++) {

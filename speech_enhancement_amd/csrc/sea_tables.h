@@ -57,6 +57,7 @@ typedef struct {
      *                      Im(2l) = x[256-2l] (k=1; lane 0's second entry is unused)
      *   fft2Nyq            byte offset of x[128] */
     unsigned fft2Addr[SEA_FFT_LSTAGES][4][32];
+    unsigned fftAddr[SEA_FFT_LSTAGES][4][SEA_LANES]; /* the same for the full-wave schedule (fftItem) */
     unsigned fft2Head[2][SEA_LANES];
     unsigned fft2Psd[2][SEA_LANES];
     unsigned fft2Nyq;
