@@ -233,6 +233,8 @@ int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
     }();
     if (single)
         hipLaunchKernelGGL(sea::ns_denoise_kernel, dim3(n_utt), dim3(64), 0, (hipStream_t)stream, a);
+    else if (n_utt > 4 * c->n_cu) /* more than four workgroups per CU: occupancy decides, not the frame period */
+        hipLaunchKernelGGL(sea::ns_denoise_pipe_big_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(sea::ns_denoise_pipe_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());

@@ -388,6 +388,7 @@ __device__ __forceinline__ void psd_from_fft2(const float *work, float *psd, con
 /* Two FRONT halves in one wave: frame A (stage buffer bufA) and frame B (bufB) are windowed,
  * transformed side by side (rfft256_dual) and reduced to their 65-bin PSDs.  actA / actB are
  * wave-uniform; an inactive side is fed zeros and its PSD is not written.  work: 512 floats. */
+template <bool ADDR_LDS>
 __device__ __forceinline__ void ns_front_dual(const float *bufA, bool actA, float *psdA, const float *bufB,
                                               bool actB, float *psdB, float *work, const Fft2Regs &fft,
                                               unsigned flags, const float (&win)[4], int lane)
@@ -400,7 +401,7 @@ __device__ __forceinline__ void ns_front_dual(const float *bufA, bool actA, floa
         eA[k] = (actA && in) ? bufA[idx] * win[k] : 0.0f;
         eB[k] = (actB && in) ? bufB[idx] * win[k] : 0.0f;
     }
-    rfft256_dual(eA, eB, work, fft, flags, lane);
+    rfft256_dual<ADDR_LDS>(eA, eB, work, fft, flags, lane);
     if (actA) psd_from_fft2(work, psdA, fft, lane);
     if (actB) psd_from_fft2(work + 256, psdB, fft, lane);
     wave_sync();

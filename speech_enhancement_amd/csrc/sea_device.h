@@ -322,17 +322,24 @@ __device__ __forceinline__ void rfft256(float e0, float e1, float e2, float e3, 
  * Same butterflies, same arithmetic; the plain and pi/4 butterflies of a block share one work item
  * (SEA_BF_PAIR) so that no level needs more than 32 lanes per transform.  work holds the two
  * frames back to back: transform A in work[0..255], B in work[256..511]. */
+/* ADDR_LDS selects where the 24 address words of a lane live: in VGPRs (fastest transform: the kernel is
+ * then bound by the longest utterance's chain of frames, which is what matters up to four workgroups
+ * per CU) or in LDS (one ds_read_b128 per level, 30 VGPRs fewer: six workgroups per CU, which is what
+ * matters for large batches). */
 struct Fft2Regs {
     unsigned kind[SEA_FFT_LSTAGES];
     unsigned addr[SEA_FFT_LSTAGES][4]; /* byte offsets of the eight operands, two per word, already moved
                                         * into the second work area for lanes >= 32 (sea_tables.h) */
+    const uint4 *addrLds;              /* ADDR_LDS: the same, [level][64 lanes] in LDS, this lane's column */
     float tw[SEA_FFT_LSTAGES][4];
     unsigned headA[2], psdA[2];        /* frame A: where this lane stores its head values / finds its PSD inputs */
     unsigned nyq;
 };
 
 
-__device__ __forceinline__ void load_fft2_regs(Fft2Regs &R, const sea_fft_tables *t, int lane)
+/* addrLds (ADDR_LDS only): SEA_FFT_LSTAGES * 64 uint4 of LDS owned by the calling wave */
+template <bool ADDR_LDS>
+__device__ __forceinline__ void load_fft2_regs(Fft2Regs &R, const sea_fft_tables *t, int lane, uint4 *addrLds)
 {
     const int j = lane & 31;
     const unsigned half = (unsigned)(lane >> 5) * 1024u; /* second transform: the next 256 words */
@@ -340,12 +347,16 @@ __device__ __forceinline__ void load_fft2_regs(Fft2Regs &R, const sea_fft_tables
 #pragma unroll
     for (int s = 0; s < SEA_FFT_LSTAGES; ++s) {
         R.kind[s] = t->fft2Item[s][j] >> 16;
+        if (ADDR_LDS)
+            addrLds[s * 64 + lane] = make_uint4(t->fft2Addr[s][0][j] + both, t->fft2Addr[s][1][j] + both,
+                                                t->fft2Addr[s][2][j] + both, t->fft2Addr[s][3][j] + both);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            R.addr[s][k] = t->fft2Addr[s][k][j] + both;
+            if (!ADDR_LDS) R.addr[s][k] = t->fft2Addr[s][k][j] + both;
             R.tw[s][k] = t->fft2Tw[s][k][j];
         }
     }
+    R.addrLds = addrLds + lane;
     R.headA[0] = t->fft2Head[0][lane];
     R.headA[1] = t->fft2Head[1][lane];
     R.psdA[0] = t->fft2Psd[0][lane];
@@ -353,11 +364,17 @@ __device__ __forceinline__ void load_fft2_regs(Fft2Regs &R, const sea_fft_tables
     R.nyq = t->fft2Nyq;
 }
 
-template <int S>
+template <int S, bool ADDR_LDS>
 __device__ __forceinline__ void fft2_level(float *work, const Fft2Regs &R)
 {
     const unsigned kind = R.kind[S];
-    const unsigned a01 = R.addr[S][0], a23 = R.addr[S][1], b01 = R.addr[S][2], b23 = R.addr[S][3];
+    unsigned a01, a23, b01, b23;
+    if (ADDR_LDS) {
+        const uint4 ad = R.addrLds[S * 64];
+        a01 = ad.x, a23 = ad.y, b01 = ad.z, b23 = ad.w;
+    } else {
+        a01 = R.addr[S][0], a23 = R.addr[S][1], b01 = R.addr[S][2], b23 = R.addr[S][3];
+    }
     const float x1 = fft_at(work, a01 & 0xffffu), x2 = fft_at(work, a01 >> 16);
     const float x3 = fft_at(work, a23 & 0xffffu), x4 = fft_at(work, a23 >> 16);
     const float x5 = fft_at(work, b01 & 0xffffu), x6 = fft_at(work, b01 >> 16);
@@ -438,35 +455,38 @@ __device__ __forceinline__ void rfft256_head(float e0, float e1, float e2, float
  * The transform is offered in two halves so that a pipelined kernel can run them in different
  * waves (one frame apart): _lo = register-resident start + levels n2 = 8, 16, 32; _hi = levels
  * n2 = 64, 128, 256.  Both end with wave_sync(). */
+template <bool ADDR_LDS>
 __device__ __forceinline__ void rfft256_dual_lo(const float (&eA)[4], const float (&eB)[4], float *work,
                                                 const Fft2Regs &R, unsigned flags, int lane)
 {
     rfft256_head(eA[0], eA[1], eA[2], eA[3], work, flags, R.headA);
     rfft256_head(eB[0], eB[1], eB[2], eB[3], work + 256, flags, R.headA);
     wave_sync();
-    fft2_level<0>(work, R);
+    fft2_level<0, ADDR_LDS>(work, R);
     wave_sync();
-    fft2_level<1>(work, R);
+    fft2_level<1, ADDR_LDS>(work, R);
     wave_sync();
-    fft2_level<2>(work, R);
+    fft2_level<2, ADDR_LDS>(work, R);
     wave_sync();
 }
 
+template <bool ADDR_LDS>
 __device__ __forceinline__ void rfft256_dual_hi(float *work, const Fft2Regs &R)
 {
-    fft2_level<3>(work, R);
+    fft2_level<3, ADDR_LDS>(work, R);
     wave_sync();
-    fft2_level<4>(work, R);
+    fft2_level<4, ADDR_LDS>(work, R);
     wave_sync();
-    fft2_level<5>(work, R);
+    fft2_level<5, ADDR_LDS>(work, R);
     wave_sync();
 }
 
+template <bool ADDR_LDS>
 __device__ __forceinline__ void rfft256_dual(const float (&eA)[4], const float (&eB)[4], float *work,
                                              const Fft2Regs &R, unsigned flags, int lane)
 {
-    rfft256_dual_lo(eA, eB, work, R, flags, lane);
-    rfft256_dual_hi(work, R);
+    rfft256_dual_lo<ADDR_LDS>(eA, eB, work, R, flags, lane);
+    rfft256_dual_hi<ADDR_LDS>(work, R);
 }
 
 /* float -> int16 exactly as the reference's (short) cast behaves on x86-64: truncate toward zero

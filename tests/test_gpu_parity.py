@@ -547,3 +547,22 @@ def test_ns_stream_plugin_flags_vs_oracle(oracle):
         assert np.array_equal(flags[b], want_flags), np.nonzero(flags[b] != want_flags)[0][:5]
         assert np.array_equal(counter[b], tr["flags"][:, 4])
         assert np.array_equal(out[b, 4:].reshape(-1).view(np.uint32), ns["den_f32"].view(np.uint32))
+
+
+def test_ns_large_batch_kernel_form(oracle):
+    """More than four utterances per CU selects the lower-register form of the pipelined kernel
+    (transform address tables in LDS): same results."""
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    torch = _torch()
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    n = 4 * n_cu + 8
+    base = [corpus.synth_utterance(90 + k, 800 + 80 * (k % 7)) for k in range(16)]
+    utts = [base[k % 16] for k in range(n)]
+    batch = sea.PackedBatch.from_arrays(utts)
+    out, _, _ = sea.ns_denoise_batch(batch)
+    torch.cuda.synchronize()
+    got = batch.split(out, full_frames_only=True)
+    want = [oracle.etsi_denoise(x)[: len(x) // 80 * 80] for x in base]
+    for k in range(n):
+        assert np.array_equal(got[k], want[k % 16]), f"utterance {k}"
