@@ -56,7 +56,7 @@ constexpr int kPipeWaves = 4;
 /* timing-only diagnostic (-DSEA_NS_TIMING): shader-clock cycles each role of workgroup 0 spends
  * working / waiting at the frame barrier -> g_ns_timing[role*2 + {0,1}] */
 #ifdef SEA_NS_TIMING
-__device__ unsigned long long g_ns_timing[16]; /* [8..15]: checkpoints inside S */
+__device__ unsigned long long g_ns_timing[24]; /* [8..15]: checkpoints inside S */
 struct RoleTimer {
     unsigned long long work = 0, wait = 0, t0 = 0, t1 = 0;
     __device__ __forceinline__ void begin() { t0 = clock64(); }
@@ -208,8 +208,10 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
         uint32_t nextw = (lane < 40 && nfr > 0) ? in32[lane] : 0u;
         int tick = 0; /* frames seen since (and including) the first non-zero one */
         int onset = (int)nfr;
+        NS_T_CK_DECL;
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
+            NS_T_CK_START;
             /* stage 0, frame i */
             bool actA = false;
             Rec01 &rA = L.r01[i & 1];
@@ -247,17 +249,22 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                     rB.tick = tB;
                 }
             }
+            NS_T_CK(5);
             if (actA || actB) {
                 wave_sync();
                 ns_front_dual<ADDR_LDS>(L.circ[0] + window_base(tick), actA, rA.psd, L.circ[1] + window_base(tB), actB, rB.psd,
                               L.work, fft, flags, win, lane);
             }
+            NS_T_CK(6);
             NS_T_MID;
             block_sync();
             NS_T_END;
         }
         if (FD && a.onset_out && lane == 0) a.onset_out[u] = onset;
         NS_T_FLUSH(0);
+#ifdef SEA_NS_TIMING
+        if (blockIdx.x == 0 && lane == 0) { g_ns_timing[16] = ck_[5]; g_ns_timing[17] = ck_[6]; }
+#endif
     } else if (role == 1) {
         /* ---- B0: BACK of stage 0; its 80 outputs enter the stage-1 buffer ---- */
         NsConst C;
@@ -439,6 +446,6 @@ __global__ __launch_bounds__(256, SEA_NS_MIN_WAVES) void ns_denoise_pipe_fd_kern
 #ifdef SEA_NS_TIMING
 extern "C" int sea_debug_ns_timing(unsigned long long *out8)
 {
-    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(sea::g_ns_timing), 16 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(sea::g_ns_timing), 24 * sizeof(unsigned long long));
 }
 #endif
