@@ -86,6 +86,12 @@ int sea_compceps_frames(const float *d_data201, float *d_coef14, long long nfram
 int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const long long *d_lengths,
                        const int *d_first_out, const long long *d_ceps_cum, long long total_frames,
                        float *d_ceps, int *d_n_ceps, int n_utt, void *stream);
+/* sea_ns_denoise_batch picks one of several forms of the same kernel by batch size (all bit-identical):
+ * 3 = six waves per utterance (up to 2 utterances per CU: shortest frame period), 2 = four waves (up to
+ * 4 per CU), 4 = four waves, lower register use (larger batches), 1 = one wave per utterance.
+ * sea_ns_kernel_form(f) forces form f for later calls (0 = by batch size again; the SEA_NS_KERNEL
+ * environment variable = single | pipe | pipe6 | big sets the initial value); returns the previous one. */
+int sea_ns_kernel_form(int form);
 /* SURVEY 8(f) #3 -- the feature chain the reference keeps commented out (etsi/cpp/ParmInterface.c:274-311):
  * WaveProc -> CompCeps -> PostProc -> VAD, then FlushAdvProcess (:348-354).
  * Step 1: NoiseSup that also stores what the frame-dropping VAD votes over.  d_flags: one byte per

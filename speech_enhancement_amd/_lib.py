@@ -30,6 +30,7 @@ PROTOTYPES = {
     "sea_rfft256_batch": (_i, [_vp, _vp, _ll, _vp]),
     "sea_compceps_frames": (_i, [_vp, _vp, _ll, _vp]),
     "sea_compceps_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _vp]),
+    "sea_ns_kernel_form": (_i, [_i]),
     "sea_ns_denoise_batch_fd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sea_afe_features_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sea_resynth64_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),

@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -208,6 +209,30 @@ int sea_gammatone_channels(float *cf64, float *bw64, float *midEar64)
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* kernel form override: 0 = by batch size; initialised from SEA_NS_KERNEL on first use */
+static std::atomic<int> g_ns_form{-1};
+static int ns_form()
+{
+    int f = g_ns_form.load();
+    if (f < 0) {
+        const char *e = getenv("SEA_NS_KERNEL");
+        f = 0;
+        if (e && !strcmp(e, "single")) f = 1;
+        if (e && !strcmp(e, "pipe")) f = 2;
+        if (e && !strcmp(e, "pipe6")) f = 3;
+        if (e && !strcmp(e, "big")) f = 4;
+        g_ns_form.store(f);
+    }
+    return f;
+}
+
+int sea_ns_kernel_form(int form)
+{
+    const int prev = ns_form();
+    if (form >= 0 && form <= 4) g_ns_form.store(form);
+    return prev;
+}
+
 int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
                          const long long *d_offsets, const long long *d_lengths, const int *d_order,
                          int *d_first_out, int n_utt, void *stream)
@@ -225,15 +250,19 @@ int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
     a.first_out = d_first_out;
     a.tables = c->ns;
     a.n_utt = n_utt;
-    /* default: four pipelined wavefronts per utterance; SEA_NS_KERNEL=single selects the
-     * one-wavefront-per-utterance form of the same arithmetic (A/B timing, identical results) */
-    static const bool single = [] {
-        const char *e = getenv("SEA_NS_KERNEL");
-        return e && !strcmp(e, "single");
-    }();
-    if (single)
+    /* Three forms of the same arithmetic (identical results), chosen by how many utterances share a CU:
+     *   <= 2 per CU  six waves per utterance: shortest frame period (the run time is one utterance's
+     *                chain of frames)                                     SEA_NS_KERNEL=pipe6
+     *   <= 4 per CU  four waves, transform address tables in VGPRs       SEA_NS_KERNEL=pipe
+     *   more         four waves, tables in LDS: six workgroups per CU     SEA_NS_KERNEL=big
+     * SEA_NS_KERNEL=single: one wave per utterance (the streaming plug-in's kernel), for A/B. */
+    const int forced = ns_form();
+    const int form = forced ? forced : (n_utt <= 2 * c->n_cu ? 3 : (n_utt <= 4 * c->n_cu ? 2 : 4));
+    if (form == 1)
         hipLaunchKernelGGL(sea::ns_denoise_kernel, dim3(n_utt), dim3(64), 0, (hipStream_t)stream, a);
-    else if (n_utt > 4 * c->n_cu) /* more than four workgroups per CU: occupancy decides, not the frame period */
+    else if (form == 3)
+        hipLaunchKernelGGL(sea::ns_denoise_pipe6_kernel, dim3(n_utt), dim3(384), 0, (hipStream_t)stream, a);
+    else if (form == 4)
         hipLaunchKernelGGL(sea::ns_denoise_pipe_big_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(sea::ns_denoise_pipe_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
@@ -263,7 +292,10 @@ int sea_ns_denoise_batch_fd(const short *d_in, short *d_out, float *d_out_f32,
     a.n_utt = n_utt;
     a.flags_out = d_flags;
     a.onset_out = d_onset;
-    hipLaunchKernelGGL(sea::ns_denoise_pipe_fd_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
+    if (n_utt <= 2 * c->n_cu)
+        hipLaunchKernelGGL(sea::ns_denoise_pipe6_fd_kernel, dim3(n_utt), dim3(384), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(sea::ns_denoise_pipe_fd_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -586,6 +586,55 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     }
 }
 
+/* ---- the second-stage BACK half cut in two (six-wave kernel, ns_pipe6_kernel.hip) -------------------
+ * ns_noise1 (wave N1): PSDMean, the non-VAD noise tracking of all 65 bins, the in-order sum of the
+ *   noise spectrum and the gain-factor scalars (NoiseSup.c:289-303, :486-517, :600-637).  None of it
+ *   depends on the Wiener gains, so it runs one frame ahead of ns_gain1.  Writes P[0..64] (mean PSD),
+ *   noise[0..64] and returns alfaGF; the caller has loaded s.denEn0..2.
+ * ns_gain1 (wave G1): the gains of all bins from (P, PSD, noise), mel filter bank, gain
+ *   factorisation of the 25 mel gains, IDCT, FIR (:522-560, MelProc.c, :639-640, :324-340). */
+__device__ __forceinline__ float ns_noise1(const float *psd, float *Pout, float *noiseOut, NsRegs &s, float eps,
+                                           int lane)
+{
+    const float nSigLo = psd[lane], nSigHi = psd[64];
+    const float PLo = (s.prevLo[1] + nSigLo) * 0.5f;
+    const float PHi = (s.prevHi[1] + nSigHi) * 0.5f;
+    s.prevLo[1] = nSigLo;
+    s.prevHi[1] = nSigHi;
+    {
+        int nb = s.nbFrame[1];
+        if (nb < 2147483647) nb++;
+        s.nbFrame[1] = nb;
+    }
+    const int nb16 = (int)(short)s.nbFrame[1];
+    noise_track1(PLo, s.noiseLo[1], nb16, eps);
+    noise_track1(PHi, s.noiseHi[1], nb16, eps);
+    Pout[lane] = PLo;
+    noiseOut[lane] = s.noiseLo[1];
+    if (lane == 0) {
+        Pout[64] = PHi;
+        noiseOut[64] = s.noiseHi[1];
+    }
+    wave_sync();
+    const float total = serial_sum<65>(noiseOut, 0.0f);
+    gain_fact_update(s, total);
+    return s.alfaGF;
+}
+
+__device__ __forceinline__ void ns_gain1(const float *psd, const float *P, const float *noise, float alfaGF,
+                                         const float *buf, BackLds &B, NsRegs &s, const NsConst &C, float *dst,
+                                         int lane, const float *idctLds)
+{
+    const float WLo = gain_bin(sqrtf(P[lane]), sqrtf(psd[lane]), noise[lane], s.denLo[1]);
+    const float WHi = gain_bin(sqrtf(P[64]), sqrtf(psd[64]), noise[64], s.denHi[1]);
+    B.wbuf[lane] = WLo;
+    if (lane == 0) B.wbuf[64] = WHi;
+    wave_sync();
+    float melOut = ns_mel_fb(B, C, lane);
+    melOut = (float)((double)(alfaGF * melOut) + (1.0 - (double)alfaGF) * 1.0);
+    ns_idct_fir<true>(melOut, B, C, buf, dst, lane, idctLds);
+}
+
 /* One whole stage on the single-wave form: stage 0 deposits its 80 output samples in
  * ring[1][240..319], stage 1 in outb[0..79]. */
 template <int ST, bool FD = false>

@@ -1,0 +1,387 @@
+/*
+ * ns_pipe6_kernel.hip -- etsi_denoise over a packed batch, SIX pipelined wavefronts per utterance.
+ *
+ * Same arithmetic as ns_pipe_kernel.hip (four waves), cut finer.  With up to four utterances per CU the
+ * run time of a launch is the longest utterance's chain of frames, i.e. (number of frames) x (frame
+ * period of one workgroup), and the frame period is the longest role.  The role timers of the
+ * four-wave kernel (tools/ns_timing.py) read F 4670, B0 3590, B1 4690, S 4310 clk; here the dual
+ * transform is cut at its middle level and the second-stage back half into noise tracking | gains:
+ *
+ *   wave FA  iteration i: load int16 frame i, zero-frame gate, push; window + register-resident start
+ *            + levels n2 = 8, 16, 32 of BOTH transforms (stage 0 of frame i, stage 1 of frame i-3)
+ *   wave FB  i+1 / i+4:   levels n2 = 64, 128, 256 and the two 65-bin PSDs
+ *   wave B0  frame i-2:   stage-0 FilterCalc, VAD, mel, IDCT, FIR -> stage-1 buffer
+ *   wave N1  frame i-5:   stage-1 PSD mean, noise tracking, in-order noise sum, gain-factor scalars
+ *   wave G1  frame i-6:   stage-1 Wiener gains, mel, gain factorisation, IDCT, FIR
+ *   wave S   the lane-grouped scalar chains: VAD log-energy of the frame pushed at i-1, in-order sum of
+ *            denSigSE1 of frame i-3, DC-offset recurrence + cast + store of frame i-7
+ *
+ * All records between neighbouring stages are double-buffered by frame parity (written at one
+ * iteration, read at the next); the two transform work areas alternate between FA and FB.
+ */
+#include "ns_core.h"
+
+namespace sea {
+
+namespace {
+
+constexpr int kSlots = 8;
+constexpr int kSlotLen = SEA_HOP;
+constexpr int kCirc = kSlots * kSlotLen;
+constexpr int kMirror = 3 * kSlotLen;
+constexpr int kWaves = 6;
+constexpr int kDepth = 7; /* S stores frame i - kDepth */
+
+struct __attribute__((aligned(16))) RecA { /* FA -> FB, S: what was pushed at this iteration */
+    int valid, tick;      /* stage 0, frame i */
+    int valid1, tick1;    /* stage 1, frame i-3 */
+};
+struct __attribute__((aligned(16))) RecPsd { /* FB -> B0 (stage 0) / N1 (stage 1) */
+    float psd[68];
+    int valid, tick, pad0, pad1;
+};
+struct __attribute__((aligned(16))) RecDen { /* B0 -> FA (valid / tick of the stage-1 frame), S (den) */
+    float den[68];
+    int valid, tick, pad0, pad1;
+};
+struct __attribute__((aligned(16))) RecN { /* N1 -> G1 */
+    float psd[68], P[68], noise[68];
+    float alfa;
+    int produced, tick, pad0;
+};
+struct __attribute__((aligned(16))) RecOut { /* G1 -> S */
+    float out[80]; /* second-stage filter output before the DC-offset filter */
+    int produced, tick, pad0, pad1;
+};
+
+struct __attribute__((aligned(16))) Pipe6Lds {
+    float circ[2][kCirc + kMirror];
+    float work[2][512];             /* transform work areas: FA fills [i & 1], FB finishes [(i-1) & 1] */
+    BackLds back[2];                /* scratch of B0 and G1 */
+    float ssq[80], sdif[80], sout[80], sjunk[160], szero[4]; /* scratch of S */
+    float frameEn[kSlots], denSum[kSlots];
+    int fdFlags[kSlots];
+    float idctT[SEA_NMEL * 16];
+    RecA ra[2];
+    RecPsd p0[2], p1[2];
+    RecDen rd[2];
+    RecN rn[2];
+    RecOut ro[2];
+};
+
+__device__ __forceinline__ int window_base(int tick) { return ((tick - 3) & (kSlots - 1)) * kSlotLen; }
+
+__device__ __forceinline__ void slot_store(float *circ, int tick, int lane, float a, float b)
+{
+    const int slot = tick & (kSlots - 1);
+    float *p = circ + slot * kSlotLen + 2 * lane;
+    *reinterpret_cast<float2 *>(p) = make_float2(a, b);
+    if (slot < 3) *reinterpret_cast<float2 *>(p + kCirc) = make_float2(a, b);
+}
+
+__device__ __forceinline__ void block_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables *t, int lane)
+{
+    C.melStart = t->melStart[lane];
+    C.melLen = t->melLen[lane];
+#pragma unroll
+    for (int i = 0; i < SEA_MEL_TAPS; ++i) C.melW[i] = t->melW[i][lane];
+    C.irWin = t->irWin[lane];
+    C.eps = t->eps;
+}
+
+} // namespace
+
+template <bool FD>
+__device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a)
+{
+    __shared__ Pipe6Lds L;
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    const long long off = a.offsets[u];
+    const long long nfr = a.lengths[u] / SEA_HOP;
+    const long long niter = nfr + kDepth;
+
+    for (int i = threadIdx.x; i < 2 * (kCirc + kMirror); i += 64 * kWaves) (&L.circ[0][0])[i] = 0.0f;
+    for (int i = threadIdx.x; i < SEA_NMEL * 16; i += 64 * kWaves) L.idctT[i] = a.tables->idct[i >> 4][i & 15];
+    if (threadIdx.x < 4) L.szero[threadIdx.x] = 0.0f;
+    if (threadIdx.x < kSlots) {
+        L.frameEn[threadIdx.x] = 0.0f;
+        L.denSum[threadIdx.x] = 0.0f;
+    }
+    if (threadIdx.x < 2) {
+        const int k = threadIdx.x;
+        L.ra[k].valid = L.ra[k].valid1 = 0;
+        L.p0[k].valid = L.p1[k].valid = 0;
+        L.rd[k].valid = 0;
+        L.rd[k].den[65] = L.rd[k].den[66] = L.rd[k].den[67] = 0.0f; /* read as zeros by S */
+        L.rn[k].produced = 0;
+        L.ro[k].produced = 0;
+    }
+    block_sync();
+
+    if (role == 0) {
+        /* ---- FA: input + zero-frame gate (ParmInterface.c:244-251); first half of both transforms ---- */
+        Fft2Regs fft;
+        load_fft2_regs<false>(fft, &a.tables->fft, lane, nullptr);
+        const unsigned flags = a.tables->fft.fftFlags[lane];
+        float win[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) win[k] = a.tables->win[k][lane];
+        const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in + off);
+        uint32_t nextw = (lane < 40 && nfr > 0) ? in32[lane] : 0u;
+        int tick = 0; /* frames seen since (and including) the first non-zero one */
+        int onset = (int)nfr;
+        for (long long i = 0; i < niter; ++i) {
+            RecA &r = L.ra[i & 1];
+            int valid = 0;
+            bool actA = false;
+            if (i < nfr) {
+                const uint32_t w = nextw;
+                if (i + 1 < nfr && lane < 40) nextw = in32[(i + 1) * 40 + lane];
+                const bool any = __ballot(w != 0u) != 0ull;
+                if (any || tick > 0) {
+                    valid = 1;
+                    if (FD && tick == 0) onset = (int)i;
+                    tick++;
+                    const float x0 = (float)(short)(w & 0xFFFFu), x1 = (float)(short)(w >> 16);
+                    if (lane < 40) slot_store(L.circ[0], tick, lane, x0, x1);
+                    actA = tick >= 3; /* NoiseSup.c:1152 */
+                }
+            }
+            /* stage 1, frame i-3 (B0 finished it at the previous iteration): NoiseSup.c:1178 <=> tick >= 5 */
+            const long long f1 = i - 3;
+            int valid1 = 0, t1 = 0;
+            bool actB = false;
+            if (f1 >= 0 && f1 < nfr) {
+                const RecDen &d = L.rd[f1 & 1];
+                valid1 = d.valid;
+                t1 = d.tick;
+                actB = valid1 && t1 >= 5;
+            }
+            if (lane == 0) {
+                r.valid = valid;
+                r.tick = tick;
+                r.valid1 = valid1;
+                r.tick1 = t1;
+            }
+            if (actA || actB) {
+                wave_sync();
+                float eA[4], eB[4];
+                const float *bufA = L.circ[0] + window_base(tick), *bufB = L.circ[1] + window_base(t1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int idx = 60 + lane + 64 * k;
+                    const bool in = (k < 3) || (lane < 8);
+                    eA[k] = (actA && in) ? bufA[idx] * win[k] : 0.0f;
+                    eB[k] = (actB && in) ? bufB[idx] * win[k] : 0.0f;
+                }
+                rfft256_dual_lo<false>(eA, eB, L.work[i & 1], fft, flags, lane);
+            }
+            block_sync();
+        }
+        if (FD && a.onset_out && lane == 0) a.onset_out[u] = onset;
+    } else if (role == 1) {
+        /* ---- FB: second half of both transforms, FFTtoPSD ---- */
+        Fft2Regs fft;
+        load_fft2_regs<false>(fft, &a.tables->fft, lane, nullptr);
+        for (long long i = 0; i < niter; ++i) {
+            const long long g = i - 1; /* FA's iteration */
+            if (g >= 0) {
+                const RecA &r = L.ra[g & 1];
+                const long long f0 = g, f1 = g - 3;
+                const int valid = r.valid, t0 = r.tick, valid1 = r.valid1, t1 = r.tick1;
+                const bool actA = (f0 < nfr) && valid && t0 >= 3;
+                const bool actB = (f1 >= 0 && f1 < nfr) && valid1 && t1 >= 5;
+                float *work = L.work[g & 1];
+                if (actA || actB) {
+                    rfft256_dual_hi<false>(work, fft);
+                    if (actA) psd_from_fft2(work, L.p0[f0 & 1].psd, fft, lane);
+                    if (actB) psd_from_fft2(work + 256, L.p1[f1 & 1].psd, fft, lane);
+                    wave_sync();
+                }
+                if (lane == 0) {
+                    if (f0 < nfr) {
+                        L.p0[f0 & 1].valid = valid;
+                        L.p0[f0 & 1].tick = t0;
+                    }
+                    if (f1 >= 0 && f1 < nfr) {
+                        L.p1[f1 & 1].valid = valid1;
+                        L.p1[f1 & 1].tick = t1;
+                    }
+                }
+            }
+            block_sync();
+        }
+    } else if (role == 2) {
+        /* ---- B0: BACK of stage 0; its 80 outputs enter the stage-1 buffer ---- */
+        NsConst C;
+        load_back_const(C, a.tables, lane);
+        NsRegs s;
+        regs_init(s, C.eps);
+        NsFd fd;
+        fd_init(fd);
+        for (long long i = 0; i < niter; ++i) {
+            const long long f = i - 2;
+            if (f >= 0 && f < nfr) {
+                const RecPsd &r = L.p0[f & 1];
+                RecDen &o = L.rd[f & 1];
+                const int valid = r.valid, t = r.tick;
+                if (valid && t >= 3) {
+                    float *tmp = L.back[0].sq;
+                    int bits = 0;
+                    ns_back<0, true, FD>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
+                                         L.frameEn[t & (kSlots - 1)], o.den, L.idctT, &fd, &bits);
+                    if (FD && lane == 0) L.fdFlags[t & (kSlots - 1)] = bits;
+                    if (lane < 40) {
+                        const float2 v = *reinterpret_cast<const float2 *>(tmp + 2 * lane);
+                        slot_store(L.circ[1], t, lane, v.x, v.y);
+                    }
+                }
+                if (lane == 0) {
+                    o.valid = valid;
+                    o.tick = t;
+                }
+            }
+            block_sync();
+        }
+    } else if (role == 3) {
+        /* ---- N1: stage-1 noise tracking, noise-spectrum sum, gain-factor scalars ---- */
+        const float eps = a.tables->eps;
+        NsRegs s;
+        regs_init(s, eps);
+        for (long long i = 0; i < niter; ++i) {
+            const long long f = i - 5;
+            if (f >= 0 && f < nfr) {
+                const RecPsd &r = L.p1[f & 1];
+                RecN &o = L.rn[f & 1];
+                const int valid = r.valid, t = r.tick;
+                int produced = 0;
+                if (valid && t >= 5) {
+                    /* denEn1[0..2] (NoiseSup.c:595-598) = sums of denSigSE1 of ticks t-2, t-1, t */
+                    s.denEn0 = L.denSum[(t - 2) & (kSlots - 1)];
+                    s.denEn1 = L.denSum[(t - 1) & (kSlots - 1)];
+                    s.denEn2 = L.denSum[t & (kSlots - 1)];
+                    o.psd[lane] = r.psd[lane];
+                    if (lane == 0) o.psd[64] = r.psd[64];
+                    const float alfa = ns_noise1(r.psd, o.P, o.noise, s, eps, lane);
+                    if (lane == 0) o.alfa = alfa;
+                    produced = 1;
+                }
+                if (lane == 0) {
+                    o.produced = produced;
+                    o.tick = t;
+                }
+            }
+            block_sync();
+        }
+    } else if (role == 4) {
+        /* ---- G1: stage-1 Wiener gains, mel, gain factorisation, IDCT, FIR ---- */
+        NsConst C;
+        load_back_const(C, a.tables, lane);
+        NsRegs s;
+        regs_init(s, C.eps);
+        for (long long i = 0; i < niter; ++i) {
+            const long long f = i - 6;
+            if (f >= 0 && f < nfr) {
+                const RecN &r = L.rn[f & 1];
+                RecOut &o = L.ro[f & 1];
+                const int produced = r.produced, t = r.tick;
+                if (produced)
+                    ns_gain1(r.psd, r.P, r.noise, r.alfa, L.circ[1] + window_base(t), L.back[1], s, C, o.out, lane, L.idctT);
+                if (lane == 0) {
+                    o.produced = produced;
+                    o.tick = t;
+                }
+            }
+            block_sync();
+        }
+    } else {
+        /* ---- S: the lane-grouped scalar chains (helper_chains) ---- */
+        uint32_t *out32 = reinterpret_cast<uint32_t *>(a.out + off);
+        float *outf = a.out_f32 ? a.out_f32 + off : nullptr;
+        float dcX = 0.0f, dcY = 0.0f; /* prevSamples, NoiseSup.c:908-909 */
+        int firstOut = -1;
+        for (long long i = 0; i < niter; ++i) {
+            /* (1) VAD log-energy (NoiseSup.c:386-391) of the frame pushed at i-1 = tick tp ("current frame" of
+             *     tick tp+2); (2) in-order sum of denSigSE1 of the frame B0 finished at i-1; (3) DC-offset
+             *     filter, int16 cast, store of the frame G1 finished at i-1 */
+            const long long fp = i - 1, fd = i - 3, fo = i - kDepth;
+            bool doVad = false, doDen = false, produced = false;
+            int tp = 0, td = 0;
+            const float *denSrc = L.rd[0].den;
+            if (fp >= 0 && fp < nfr) {
+                const RecA &r = L.ra[fp & 1];
+                doVad = r.valid != 0;
+                tp = r.tick;
+            }
+            if (fd >= 0 && fd < nfr) {
+                const RecDen &r = L.rd[fd & 1];
+                doDen = r.valid && r.tick >= 3;
+                td = r.tick;
+                denSrc = r.den;
+            }
+            const bool haveOut = fo >= 0 && fo < nfr;
+            if (haveOut) produced = L.ro[fo & 1].produced != 0;
+            if (doVad) {
+                const float *frame = L.circ[0] + (tp & (kSlots - 1)) * kSlotLen;
+                const float x = frame[lane];
+                L.ssq[lane] = x * x;
+                if (lane < 16) {
+                    const float yv = frame[64 + lane];
+                    L.ssq[64 + lane] = yv * yv;
+                }
+            }
+            if (produced) {
+                const float *y2 = L.ro[fo & 1].out;
+                const float xm1 = (lane == 0) ? dcX : y2[lane - 1];
+                L.sdif[lane] = y2[lane] - xm1;
+                if (lane < 16) L.sdif[64 + lane] = y2[64 + lane] - y2[63 + lane];
+                dcX = y2[79];
+            }
+            if (doVad || doDen || produced) {
+                wave_sync();
+                float vadSum, denTotal, y = dcY;
+                helper_chains(L.ssq, denSrc, L.sdif, L.sout, L.sjunk, L.szero, vadSum, denTotal, y, lane);
+                if (doVad) {
+                    const float en = vad_frame_energy(vadSum);
+                    if (lane == 0) L.frameEn[(tp + 2) & (kSlots - 1)] = en;
+                }
+                if (doDen && lane == 0) L.denSum[td & (kSlots - 1)] = denTotal;
+                if (produced) {
+                    dc_verify(L.sdif, L.sout, dcY, y, lane);
+                    dcY = y;
+                    if (firstOut < 0) firstOut = (int)fo;
+                }
+            }
+            if (haveOut) {
+                if (lane < 40) {
+                    uint32_t packed = 0u;
+                    if (produced) {
+                        const float2 v = *reinterpret_cast<const float2 *>(&L.sout[2 * lane]);
+                        packed = (uint32_t)cast_i16(v.x) | ((uint32_t)cast_i16(v.y) << 16);
+                        if (outf) *reinterpret_cast<float2 *>(outf + fo * SEA_HOP + 2 * lane) = v;
+                    }
+                    out32[fo * 40 + lane] = packed;
+                }
+                if (FD && produced && lane == 0 && a.flags_out)
+                    a.flags_out[off / 8 + 10 * fo] = (unsigned char)L.fdFlags[L.ro[fo & 1].tick & (kSlots - 1)];
+                wave_sync();
+            }
+            block_sync();
+        }
+        if (a.first_out && lane == 0) a.first_out[u] = firstOut;
+    }
+}
+
+__global__ __launch_bounds__(384, 6) void ns_denoise_pipe6_kernel(NsBatchArgs a) { ns_pipe6_body<false>(a); }
+__global__ __launch_bounds__(384, 6) void ns_denoise_pipe6_fd_kernel(NsBatchArgs a) { ns_pipe6_body<true>(a); }
+
+} // namespace sea

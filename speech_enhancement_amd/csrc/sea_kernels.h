@@ -102,7 +102,9 @@ __global__ void subband_kernel(SubbandArgs a);
 __global__ void ns_denoise_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_big_kernel(NsBatchArgs a); /* lower-register form for > 4 utterances per CU */
-__global__ void ns_denoise_pipe_fd_kernel(NsBatchArgs a); /* + speech flags for the frame-dropping VAD */
+__global__ void ns_denoise_pipe_fd_kernel(NsBatchArgs a);
+__global__ void ns_denoise_pipe6_kernel(NsBatchArgs a);    /* six waves per utterance (ns_pipe6_kernel.hip) */
+__global__ void ns_denoise_pipe6_fd_kernel(NsBatchArgs a); /* + speech flags for the frame-dropping VAD */
 __global__ void ns_stream_kernel(NsStreamArgs a);
 __global__ void ns_stream_fd_kernel(NsStreamArgs a);
 __global__ void selftest_pi4_kernel(unsigned long long *mismatches);

@@ -566,3 +566,26 @@ def test_ns_large_batch_kernel_form(oracle):
     want = [oracle.etsi_denoise(x)[: len(x) // 80 * 80] for x in base]
     for k in range(n):
         assert np.array_equal(got[k], want[k % 16]), f"utterance {k}"
+
+
+def test_ns_all_kernel_forms_agree(oracle):
+    """sea_ns_denoise_batch chooses among four forms of the same arithmetic by batch size (six waves
+    per utterance / four waves / four waves with less register use / one wave): forced one by one on
+    the mixed corpus, every form matches the oracle bit for bit."""
+    import speech_enhancement_amd as sea
+    torch = _torch()
+    lib = sea.load()
+    utts = _mixed_corpus()
+    batch = sea.PackedBatch.from_arrays(utts)
+    want = [oracle.etsi_denoise(x)[: len(x) // 80 * 80] for x in utts]
+    prev = lib.sea_ns_kernel_form(0)
+    try:
+        for form in (1, 2, 3, 4):
+            lib.sea_ns_kernel_form(form)
+            out, f32, first = sea.ns_denoise_batch(batch, want_f32=True)
+            torch.cuda.synchronize()
+            got = batch.split(out, full_frames_only=True)
+            for u in range(len(utts)):
+                assert np.array_equal(got[u], want[u]), f"form {form}, utterance {u}"
+    finally:
+        lib.sea_ns_kernel_form(prev)
