@@ -326,6 +326,10 @@ __device__ __forceinline__ void rfft256(float e0, float e1, float e2, float e3, 
  * then bound by the longest utterance's chain of frames, which is what matters up to four workgroups
  * per CU) or in LDS (one ds_read_b128 per level, 30 VGPRs fewer: six workgroups per CU, which is what
  * matters for large batches). */
+#ifndef SEA_FFT_PACKED
+#define SEA_FFT_PACKED 1
+#endif
+
 struct Fft2Regs {
     unsigned kind[SEA_FFT_LSTAGES];
     unsigned addr[SEA_FFT_LSTAGES][4]; /* byte offsets of the eight operands, two per word, already moved
@@ -382,6 +386,27 @@ __device__ __forceinline__ void fft2_level(float *work, const Fft2Regs &R)
     float o1, o2, o3, o4, o5, o6, o7, o8;
     if (kind == SEA_BF_TWIDDLE) { /* rfft.c:145-174 */
         const float cc1 = R.tw[S][0], ss1 = R.tw[S][1], cc3 = R.tw[S][2], ss3 = R.tw[S][3];
+#if SEA_FFT_PACKED
+        /* the same 24 operations on register pairs (v_pk_mul_f32 / v_pk_add_f32: each half rounded like the
+         * scalar instruction; a - b == a + (-b) and the operand swaps / sign flips are instruction modifiers):
+         *   (t1,t2) = (x3,x7)*(cc1,cc1) + (x7,x3)*(ss1,-ss1)      (t3,t4) likewise from (x4,x8), cc3, ss3 */
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f a37 = {x3, x7}, a48 = {x4, x8}, w1 = {cc1, ss1}, w3 = {cc3, ss3};
+        /* the (c,c) and (s,-s) operands are selected out of the (c,s) pair by the instruction's op_sel / neg_hi
+         * fields; written as asm because the compiler otherwise materialises them (8 more registers per level) */
+        v2f p1, q1, p3, q3;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p1) : "v"(a37), "v"(w1));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(q1) : "v"(a37), "v"(w1));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p3) : "v"(a48), "v"(w3));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(q3) : "v"(a48), "v"(w3));
+        const v2f T12 = p1 + q1, T34 = p3 + q3;
+        const v2f T56 = T12 + T34, D34 = T12 - T34; /* (t5,t6), new (t3,t4) */
+        const v2f o16 = v2f{x1, x1} + v2f{T56.x, -T56.x}; /* x1 + t5, x1 - t5 */
+        const v2f o25 = v2f{x5, x5} + v2f{D34.y, -D34.y}; /* x5 + t4, x5 - t4 */
+        const v2f o83 = v2f{T56.y, T56.y} + v2f{x6, -x6}; /* x6 + t6, t6 - x6 */
+        const v2f o47 = v2f{x2, -x2} - v2f{D34.x, D34.x}; /* x2 - t3, -x2 - t3 */
+        o1 = o16.x, o6 = o16.y, o2 = o25.x, o5 = o25.y, o8 = o83.x, o3 = o83.y, o4 = o47.x, o7 = o47.y;
+#else
         float t1 = x3 * cc1 + x7 * ss1;
         float t2 = x7 * cc1 - x3 * ss1;
         float t3 = x4 * cc3 + x8 * ss3;
@@ -397,6 +422,7 @@ __device__ __forceinline__ void fft2_level(float *work, const Fft2Regs &R)
         o1 = x1 + t5;
         o5 = x5 - t4;
         o2 = x5 + t4;
+#endif
     } else { /* SEA_BF_PAIR: plain butterfly on the a-quadruple (rfft.c:110-113), pi/4 butterfly on
                 the b-quadruple (rfft.c:120-125; the exact multiply form proven in fft_level) */
         const float t1 = x4 + x3;
