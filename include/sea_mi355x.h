@@ -182,6 +182,11 @@ int sea_selftest_pi4(unsigned long long *n_mismatch);
  * inside its domain (2^-100 <= |a| <= 2^100) x all 64 divisors against the IEEE quotient.
  * out2[0] = mismatches, out2[1] = patterns tested per divisor */
 int sea_selftest_div(unsigned long long *out2);
+/* the NoiseSup gain / noise-tracking divisions inside their per-frame guarded domain (csrc/ns_core.h, ns_div:
+ * the compiler's IEEE sequence without v_div_scale / v_div_fixup, reciprocal shared per denominator) against
+ * plain division on 2^30 pseudo-random + edge-mantissa operand pairs spanning the domain, and the double
+ * reciprocal of the noise update.  out3[0] = pairs tested, out3[1] = float mismatches, out3[2] = double */
+int sea_selftest_nsdiv(unsigned long long *out3);
 /* DC-offset recurrence on ncases frames of 80 differences (host pointers): output and whether the
  * exact double path had to be taken */
 int sea_selftest_dc(const float *dif, const float *y0, float *out, int *fellback, int ncases);

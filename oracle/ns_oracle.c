@@ -659,6 +659,27 @@ void ora_compceps_frame(const float *data201, float *coef14)
 /* ------------------------------------------------------------------------------------------
  * Utterance drivers: ParmInterface.c:208-330 + AdvFrontEnd.c:125-210
  * ---------------------------------------------------------------------------------------- */
+/* DoNoiseSup on float frames, no zero-frame gate (the frame-level plugin entry, NoiseSup.c:1061):
+ * out gets 80 floats per TRUE return, produced[f] = the return value.  Returns the number of outputs. */
+long ora_ns_stream_f32(const float *in, long nframes, float *out, int *produced)
+{
+    ns_state *s = (ns_state *)malloc(sizeof *s);
+    long f, nout = 0;
+    tables_init();
+    ns_init(s);
+    for (f = 0; f < nframes; f++) {
+        float y[HOP];
+        int ok = ns_step(s, in + f * HOP, y);
+        produced[f] = ok ? 1 : 0;
+        if (ok) {
+            memcpy(out + nout * HOP, y, sizeof y);
+            nout++;
+        }
+    }
+    free(s);
+    return nout;
+}
+
 long ora_ns_trace(const short *in, long n, short *out_i16, float *den_f32, float *ceps,
                   float *scal, float *spec, long *counts)
 {

@@ -76,6 +76,16 @@ class _Lib:
                     scal=None if scal is None else scal[:nfr],
                     spec=None if spec is None else spec[:nfr], nout=nout, nceps=nceps)
 
+    def ns_stream_f32(self, frames):
+        """DoNoiseSup on float frames [n, 80] (no zero-frame gate): (out[nout*80] float32, produced[n])."""
+        x = np.ascontiguousarray(frames, dtype=np.float32).reshape(-1, 80)
+        out = np.zeros(x.size, np.float32)
+        prod = np.zeros(x.shape[0], np.int32)
+        fn = self._f("ns_stream_f32")
+        fn.restype = ctypes.c_long
+        nout = fn(_ptr(x), ctypes.c_long(x.shape[0]), _ptr(out), _ptr(prod))
+        return out[: nout * 80], prod
+
     def afe_trace(self, x):
         """The full per-frame chain: WaveProc -> CompCeps -> PostProc -> VAD + flush.
         Returns dict(flags[nfr,5] = SpeechFoundVar/Spec/Mel/VADNS + FrameCounter, feat_cc[nceps,14],

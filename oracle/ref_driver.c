@@ -16,6 +16,7 @@
  *                            records the float denoised stream, the per-frame NoiseSup state and
  *                            runs DoCompCeps exactly as the commented-out block
  *                            etsi/cpp/ParmInterface.c:275-293 would.
+ *   ref_ns_stream_f32     -> fe->DoNoiseSup (etsi/cpp/NoiseSup.c:1061) on float frames
  *   ref_afe_trace         -> the whole commented-out chain (WaveProc, CompCeps, PostProc, VAD, flush)
  */
 #include "NoiseSup.c" /* the reference TU itself: gives access to struct NoiseSupStructX */
@@ -105,6 +106,28 @@ long ref_ns_trace(const short *in, long n, short *out_i16, float *den_f32, float
     counts[0] = nout;
     counts[1] = nceps;
     return nfr;
+}
+
+/* fe->DoNoiseSup on float frames (the frame-level plugin slot, ParmInterface.h:120-178), no gate */
+long ref_ns_stream_f32(const float *in, long nframes, float *out, int *produced)
+{
+    FEParamsX *fe = AdvProcessAlloc(8000);
+    long f, nout = 0;
+    int i;
+    AdvProcessInit(fe);
+    for (f = 0; f < nframes; f++) {
+        float cur[80], y[80];
+        int ok;
+        for (i = 0; i < 80; i++) cur[i] = in[f * 80 + i];
+        ok = fe->DoNoiseSup(cur, y, fe);
+        produced[f] = ok ? 1 : 0;
+        if (ok) {
+            for (i = 0; i < 80; i++) out[nout * 80 + i] = y[i];
+            nout++;
+        }
+    }
+    AdvProcessDelete(&fe);
+    return nout;
 }
 
 /*

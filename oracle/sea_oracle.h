@@ -29,6 +29,7 @@ int ora_etsi_denoise(const short *in, short *out, long n);
 /* etsi/cpp/rfft.c:45-180 (n == 1<<m, any m >= 2) */
 void ora_rfft(float *x, int n, int m);
 /* same contract as ref_ns_trace() in ref_driver.c */
+long ora_ns_stream_f32(const float *in, long nframes, float *out, int *produced);
 long ora_afe_trace(const short *in, long n, int *flags, float *feat_cc, float *feat_pp, float *vad_out,
                    long *counts);
 long ora_ns_trace(const short *in, long n, short *out_i16, float *den_f32, float *ceps,

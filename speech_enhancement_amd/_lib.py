@@ -51,6 +51,7 @@ PROTOTYPES = {
     "sea_ns_state_floats": (_i, []),
     "sea_selftest_pi4": (_i, [_vp]),
     "sea_selftest_div": (_i, [_vp]),
+    "sea_selftest_nsdiv": (_i, [_vp]),
     "sea_selftest_dc": (_i, [_vp, _vp, _vp, _vp, _i]),
     "sea_selftest_log": (_i, [_vp, _vp, _i]),
 }

@@ -50,6 +50,10 @@ struct NsConst {
 };
 
 /* per-utterance recursive state that is not in LDS */
+#ifndef SEA_NS_FAST_DIV
+#define SEA_NS_FAST_DIV 1
+#endif
+
 struct NsRegs {
     /* per bin: [stage]; "Lo" = bin lane (0..63), "Hi" = bin 64 (meaningful in lane 0) */
     float noiseLo[2], noiseHi[2];   /* noiseSE1/2 */
@@ -63,6 +67,7 @@ struct NsRegs {
     int flagVAD, hangOver, nbSpeech; /* X_INT16 in the reference */
     int nIn1, nIn2, nOut2;
     int onset;
+    int psdOk[2];                   /* previous frame's PSD was inside the fast-division domain (ns_psd_in_domain) */
 };
 
 __device__ __forceinline__ void regs_init(NsRegs &s, float eps)
@@ -73,6 +78,7 @@ __device__ __forceinline__ void regs_init(NsRegs &s, float eps)
         s.denLo[st] = s.denHi[st] = 0.0f;
         s.prevLo[st] = s.prevHi[st] = 0.0f;
         s.nbFrame[st] = 0;
+        s.psdOk[st] = 1; /* all-zero history is inside the domain */
     }
     s.dcX = s.dcY = 0.0f;
     s.denEn0 = s.denEn1 = s.denEn2 = 0.0f;
@@ -140,6 +146,55 @@ __device__ __forceinline__ double ns_ln(double x)
  * (SURVEY F9).
  *
  * Second-stage noise tracking in the energy domain (:486-517): P = 2-frame mean PSD. */
+/* ---- IEEE division without the range scaffolding ------------------------------------------------------
+ * The compiler expands a / b into  v_div_scale x2, v_rcp, fma, fma | mul, fma, fma, fma, v_div_fmas |
+ * v_div_fixup  (11 vector instructions; a third of the BACK waves' instruction count was division).  For
+ * operands with  b normal, 1/b normal, a == 0 or |a| >= 2^-102, and -126 < exponent(a) - exponent(b) < 96
+ * both v_div_scale return their operand unchanged with VCC = 0, v_div_fmas is then a plain fma and
+ * v_div_fixup returns the quotient as it is (a == 0: the sequence below yields +0, like the fixup).  Inside
+ * that domain the SAME instruction sequence without the three scaffolding instructions gives the same bits,
+ * and the denominator-only part (rcp + 2 fma) is shared by the quotients that have a common denominator:
+ * 5 + 3 instructions instead of 11 per quotient.  ns_back() establishes the domain per frame
+ * (ns_psd_in_domain + the bounds derived in its comment) and falls back to plain division outside it;
+ * sea_selftest_nsdiv() compares both forms bit for bit over random and edge operands of the domain. */
+struct NsRcp {
+    float d, r;
+};
+__device__ __forceinline__ NsRcp ns_rcp(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __fmaf_rn(-d, r0, 1.0f);
+    return NsRcp{d, __fmaf_rn(e, r0, r0)};
+}
+__device__ __forceinline__ float ns_div(float n, const NsRcp &R)
+{
+    float q = n * R.r;
+    float e = __fmaf_rn(-R.d, q, n);
+    q = __fmaf_rn(e, R.r, q);
+    e = __fmaf_rn(-R.d, q, n);
+    return __fmaf_rn(e, R.r, q);
+}
+/* 1.0 / d in double for 1 <= d < 2^512: the compiler's sequence (rcp, 4 fma, mul, fma, fmas) with the
+ * multiply by the numerator 1.0 dropped (exact) */
+__device__ __forceinline__ double ns_inv64(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __fma_rn(-d, r, 1.0);
+    r = __fma_rn(r, e, r);
+    e = __fma_rn(-d, r, 1.0);
+    r = __fma_rn(r, e, r);
+    e = __fma_rn(-d, r, 1.0);
+    return __fma_rn(e, r, r);
+}
+/* the per-frame domain test: a PSD value that is 0 or in [2^-40, 2^48] (NaN, Inf, negative: false); full-scale
+ * int16 audio reaches (200 * 32768)^2 = 2^45.3 */
+__device__ __forceinline__ bool ns_psd_in_domain(float v)
+{
+    const unsigned lo = 0x2B800000u /* 2^-40 */, hi = 0x57800000u /* 2^48 */;
+    return (v == 0.0f) || ((__float_as_uint(v) - lo) <= (hi - lo));
+}
+
+template <bool FAST>
 __device__ __forceinline__ void noise_track1(float P, float &noise, int nb, float eps)
 {
     float n2 = noise * noise;
@@ -147,8 +202,11 @@ __device__ __forceinline__ void noise_track1(float P, float &noise, int nb, floa
         const float lambda = 1 - 1 / (float)nb;
         n2 = lambda * n2 + (1 - lambda) * P;
     } else {
-        const float r1 = P / (P + n2), r2 = P / n2;
-        const float upd = (float)(0.9 + 0.1 * (double)r1 * (1.0 + 1.0 / (1.0 + 0.1 * (double)r2)));
+        /* FAST: P in {0} u [2^-41, 2^48], n2 in [2^-30, 2^57] -> exponent differences within [-99, 78] */
+        const float r1 = FAST ? ns_div(P, ns_rcp(P + n2)) : P / (P + n2);
+        const float r2 = FAST ? ns_div(P, ns_rcp(n2)) : P / n2;
+        const double inv = FAST ? ns_inv64(1.0 + 0.1 * (double)r2) : 1.0 / (1.0 + 0.1 * (double)r2);
+        const float upd = (float)(0.9 + 0.1 * (double)r1 * (1.0 + inv));
         n2 *= upd;
     }
     n2 = sqrtf(n2);
@@ -156,10 +214,26 @@ __device__ __forceinline__ void noise_track1(float P, float &noise, int nb, floa
 }
 
 /* Wiener gain of one bin given the (already updated) noise magnitude (:522-526, :551-560).
- * Psqrt = sqrt of the mean PSD, nSigSqrt = sqrt of this frame's PSD. */
+ * Psqrt = sqrt of the mean PSD, nSigSqrt = sqrt of this frame's PSD.
+ * FAST domain (see ns_back): Psqrt, nSigSqrt in {0} u [2^-20.5, 2^24], den in {0} u [2^-24, 2^24], noise in
+ * [2^-15, 2^29]  ->  prio in {0} u [2^-54, 2^40] (post > 0 implies post >= 2^-23), W in {0} u [2^-55, 1],
+ * W * Psqrt in {0} u [2^-75.5, 2^24]; every numerator is 0 or >= 2^-76, every exponent difference is within
+ * [-105, 40].  The returned den = W2 * nSigSqrt with W2 in [0.0736, 1] is 0 or in [2^-24, 2^24] again. */
+template <bool FAST>
 __device__ __forceinline__ float gain_bin(float Psqrt, float nSigSqrt, float noise, float &den)
 {
     const float beta = (float)0.98, rsbMin = (float)0.079432823;
+    if (FAST) {
+        const NsRcp rn = ns_rcp(noise);
+        const float post = ns_div(Psqrt, rn) - 1;
+        float prio = beta * ns_div(den, rn) + (1 - beta) * ((0 > post) ? 0 : post);
+        float W = ns_div(prio, ns_rcp(1 + prio));
+        prio = ns_div(W * Psqrt, rn);
+        prio = (prio > rsbMin) ? prio : rsbMin;
+        W = ns_div(prio, ns_rcp(1 + prio));
+        den = W * nSigSqrt;
+        return W;
+    }
     const float post = (Psqrt / noise) - 1;
     float prio = beta * (den / noise) + (1 - beta) * ((0 > post) ? 0 : post);
     float W = prio / (1 + prio);
@@ -171,11 +245,11 @@ __device__ __forceinline__ float gain_bin(float Psqrt, float nSigSqrt, float noi
 }
 
 /* the whole bin: P = 2-frame mean PSD, nSig = this frame's PSD */
-template <int ST>
+template <int ST, bool FAST = false>
 __device__ __forceinline__ float filter_bin(float P, float nSig, float &noise, float &den, int nb,
                                             int flagVAD, float eps)
 {
-    if (ST == 1) noise_track1(P, noise, nb, eps);
+    if (ST == 1) noise_track1<FAST>(P, noise, nb, eps);
     nSig = sqrtf(nSig); /* :522-526, (float)sqrt((double)x) == correctly rounded sqrtf */
     P = sqrtf(P);
     if (ST == 0) { /* VAD-gated noise tracking in magnitude, :531-546 */
@@ -185,7 +259,7 @@ __device__ __forceinline__ float filter_bin(float P, float nSig, float &noise, f
             noise = (n < eps) ? eps : n;
         }
     }
-    return gain_bin(P, nSig, noise, den);
+    return gain_bin<FAST>(P, nSig, noise, den);
 }
 
 /* VAD frame log-energy (NoiseSup.c:386-391) from 64 + sum of the 80 squared samples: depends on
@@ -532,12 +606,23 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
      *     (same cost as one predicated lane, but branch-free, so the two independent chains
      *     interleave) --- */
     const int nb16 = (int)(short)s.nbFrame[ST];
-    const float WLo = filter_bin<ST>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
-#ifndef SEA_ABLATE_HI
-    const float WHi = filter_bin<ST>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
-#else
-    const float WHi = PHi;
-#endif
+    /* the fast-division domain (ns_div): this frame's and the previous frame's PSD in {0} u [2^-40, 2^48]
+     * (so P is 0 or in [2^-41, 2^48], and den, left by the previous frame, 0 or in [2^-24, 2^24]) and the
+     * noise magnitude in [2^-15, 2^28] (>= eps = 2^-14.4 by construction; each update keeps it below
+     * max(noise, 1.05 sqrt(P))).  Wave-uniform; always true for int16 audio ((200 * 32768)^2 = 2^45.3). */
+    const bool psdOk = __ballot(!(ns_psd_in_domain(nSigLo) && ns_psd_in_domain(nSigHi))) == 0ull;
+    const bool noiseOk =
+        __ballot(!(s.noiseLo[ST] <= 0x1p28f && s.noiseHi[ST] <= 0x1p28f && s.noiseLo[ST] >= 0x1p-15f && s.noiseHi[ST] >= 0x1p-15f)) == 0ull;
+    const bool fast = SEA_NS_FAST_DIV && psdOk && noiseOk && (s.psdOk[ST] != 0);
+    s.psdOk[ST] = psdOk ? 1 : 0;
+    float WLo, WHi;
+    if (fast) {
+        WLo = filter_bin<ST, true>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
+        WHi = filter_bin<ST, true>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
+    } else {
+        WLo = filter_bin<ST>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
+        WHi = filter_bin<ST>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
+    }
     float *spect = (PIPE && ST == 0) ? spectOut : B.sbuf;
     B.wbuf[lane] = WLo;
     spect[lane] = (ST == 0) ? s.denLo[0] : s.noiseLo[1];
@@ -607,8 +692,18 @@ __device__ __forceinline__ float ns_noise1(const float *psd, float *Pout, float 
         s.nbFrame[1] = nb;
     }
     const int nb16 = (int)(short)s.nbFrame[1];
-    noise_track1(PLo, s.noiseLo[1], nb16, eps);
-    noise_track1(PHi, s.noiseHi[1], nb16, eps);
+    /* the fast-division domain exactly as in ns_back (this wave sees every frame's PSD and owns the noise) */
+    const bool psdOk = __ballot(!(ns_psd_in_domain(nSigLo) && ns_psd_in_domain(nSigHi))) == 0ull;
+    const bool noiseOk = __ballot(!(s.noiseLo[1] <= 0x1p28f && s.noiseHi[1] <= 0x1p28f)) == 0ull;
+    const bool fast = SEA_NS_FAST_DIV && psdOk && noiseOk && (s.psdOk[1] != 0);
+    s.psdOk[1] = psdOk ? 1 : 0;
+    if (fast) {
+        noise_track1<true>(PLo, s.noiseLo[1], nb16, eps);
+        noise_track1<true>(PHi, s.noiseHi[1], nb16, eps);
+    } else {
+        noise_track1<false>(PLo, s.noiseLo[1], nb16, eps);
+        noise_track1<false>(PHi, s.noiseHi[1], nb16, eps);
+    }
     Pout[lane] = PLo;
     noiseOut[lane] = s.noiseLo[1];
     if (lane == 0) {
@@ -625,8 +720,21 @@ __device__ __forceinline__ void ns_gain1(const float *psd, const float *P, const
                                          const float *buf, BackLds &B, NsRegs &s, const NsConst &C, float *dst,
                                          int lane, const float *idctLds)
 {
-    const float WLo = gain_bin(sqrtf(P[lane]), sqrtf(psd[lane]), noise[lane], s.denLo[1]);
-    const float WHi = gain_bin(sqrtf(P[64]), sqrtf(psd[64]), noise[64], s.denHi[1]);
+    /* the fast-division domain as in ns_back: this wave sees every frame's PSD too and owns den; the noise
+     * magnitudes arrive from the N1 wave (>= eps by its clamp) */
+    const float nSigLo = psd[lane], nSigHi = psd[64], nzLo = noise[lane], nzHi = noise[64];
+    const bool psdOk = __ballot(!(ns_psd_in_domain(nSigLo) && ns_psd_in_domain(nSigHi))) == 0ull;
+    const bool noiseOk = __ballot(!(nzLo <= 0x1p29f && nzHi <= 0x1p29f)) == 0ull;
+    const bool fast = SEA_NS_FAST_DIV && psdOk && noiseOk && (s.psdOk[1] != 0);
+    s.psdOk[1] = psdOk ? 1 : 0;
+    float WLo, WHi;
+    if (fast) {
+        WLo = gain_bin<true>(sqrtf(P[lane]), sqrtf(nSigLo), nzLo, s.denLo[1]);
+        WHi = gain_bin<true>(sqrtf(P[64]), sqrtf(nSigHi), nzHi, s.denHi[1]);
+    } else {
+        WLo = gain_bin<false>(sqrtf(P[lane]), sqrtf(nSigLo), nzLo, s.denLo[1]);
+        WHi = gain_bin<false>(sqrtf(P[64]), sqrtf(nSigHi), nzHi, s.denHi[1]);
+    }
     B.wbuf[lane] = WLo;
     if (lane == 0) B.wbuf[64] = WHi;
     wave_sync();
@@ -884,6 +992,7 @@ __device__ __forceinline__ void state_store(float *blob, const NsLds &L, const N
         }
         qi[0] = s.nbFrame[0]; qi[1] = s.nbFrame[1]; qi[2] = s.flagVAD; qi[3] = s.hangOver;
         qi[4] = s.nbSpeech; qi[5] = s.nIn1; qi[6] = s.nIn2; qi[7] = s.nOut2; qi[8] = s.onset;
+        qi[10] = (s.psdOk[0] ? 1 : 0) | (s.psdOk[1] ? 2 : 0);
     }
 }
 
@@ -912,6 +1021,7 @@ __device__ __forceinline__ void state_load(const float *blob, NsLds &L, NsRegs &
     }
     s.nbFrame[0] = qi[0]; s.nbFrame[1] = qi[1]; s.flagVAD = qi[2]; s.hangOver = qi[3];
     s.nbSpeech = qi[4]; s.nIn1 = qi[5]; s.nIn2 = qi[6]; s.nOut2 = qi[7]; s.onset = qi[8];
+    s.psdOk[0] = qi[10] & 1; s.psdOk[1] = (qi[10] >> 1) & 1;
 }
 
 } // namespace

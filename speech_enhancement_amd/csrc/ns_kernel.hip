@@ -162,4 +162,46 @@ __global__ __launch_bounds__(256) void selftest_log_kernel(const float *x, doubl
     if (i < n) out[i] = ns_ln((double)x[i]);
 }
 
+/* sea_selftest_nsdiv: ns_div / ns_inv64 (ns_core.h) against the compiler's IEEE division, bit for bit, on
+ * pseudo-random and edge-mantissa operands spanning the whole domain ns_back() admits: denominators
+ * 2^-30 .. 2^59, numerators 0 or 2^-76 .. 2^49 with an exponent difference within [-106, 80]; the double
+ * reciprocal on d = 1 + 0.1 r2, r2 in {0} u [2^-100, 2^80].
+ * out[0] = float pairs tested, out[1] = float mismatches, out[2] = double mismatches */
+__device__ __forceinline__ unsigned st_hash(unsigned x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float st_float(unsigned h, int expLo, int expHi)
+{
+    const unsigned sel = h >> 29; /* mantissa: mostly random, sometimes all zeros / all ones / one bit */
+    unsigned man = st_hash(h) & 0x7fffffu;
+    if (sel == 0) man = 0;
+    if (sel == 1) man = 0x7fffffu;
+    if (sel == 2) man = 1u << (h % 23u);
+    const int e = expLo + (int)((h >> 8) % (unsigned)(expHi - expLo + 1));
+    return __uint_as_float(((unsigned)(e + 127) << 23) | man);
+}
+__global__ __launch_bounds__(256) void selftest_nsdiv_kernel(unsigned long long *out, int iters)
+{
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bad32 = 0, bad64 = 0;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned h = st_hash(tid * 2654435761u + (unsigned)it * 40503u + 1u);
+        const float b = st_float(st_hash(h ^ 0x9e3779b9u), -30, 58);
+        const int eb = (int)(__float_as_uint(b) >> 23) - 127;
+        float a = st_float(st_hash(h + 0x85ebca6bu), max(-76, eb - 106), min(48, eb + 80));
+        if ((h & 63u) == 0) a = 0.0f;
+        const float want = a / b, got = ns_div(a, ns_rcp(b));
+        bad32 += (__float_as_uint(want) != __float_as_uint(got)) ? 1 : 0;
+        float r2 = st_float(st_hash(h ^ 0x27d4eb2fu), -100, 79);
+        if ((h & 127u) == 1) r2 = 0.0f;
+        const double d = 1.0 + 0.1 * (double)r2;
+        bad64 += (__double_as_longlong(1.0 / d) != __double_as_longlong(ns_inv64(d))) ? 1 : 0;
+    }
+    if (bad32) atomicAdd(out + 1, bad32);
+    if (bad64) atomicAdd(out + 2, bad64);
+    if (tid == 0) out[0] = (unsigned long long)gridDim.x * blockDim.x * (unsigned long long)iters;
+}
+
 } // namespace sea

@@ -110,6 +110,7 @@ __global__ void ns_stream_fd_kernel(NsStreamArgs a);
 __global__ void selftest_pi4_kernel(unsigned long long *mismatches);
 __global__ void selftest_dc_kernel(const float *dif, const float *y0, float *out, int *fellback, int ncases);
 __global__ void selftest_log_kernel(const float *x, double *out, int n);
+__global__ void selftest_nsdiv_kernel(unsigned long long *out, int iters);
 __global__ void selftest_div_kernel(const sea_gt_tables *t, unsigned long long *mismatches);
 __global__ void rfft256_kernel(const float *in, float *out, long long nframes, const sea_fft_tables *t);
 __global__ void compceps_kernel(CepsArgs a);

@@ -401,6 +401,54 @@ def test_subband_vs_oracle(oracle):
     assert one.min() >= 0 and one.max() > 100      # hair-cell output is a non-negative firing rate
 
 
+def _float_stream_case(seed, nfr=60):
+    rng = np.random.default_rng(seed)
+    t = np.arange(nfr * 80)
+    x = rng.standard_normal(nfr * 80) * 800 + 2000 * np.sin(t * 0.1) * ((t // 1600) % 2)
+    return x.astype(np.float32).reshape(nfr, 80)
+
+
+def test_ns_stream_float_amplitude_extremes(oracle):
+    """DoNoiseSup takes floats of any magnitude.  The back half's guarded division (ns_div) only runs while
+    the PSD is 0 or within [2^-40, 2^48] and the noise estimate within [2^-15, 2^28]; everything else takes
+    the plain-division path.  Streams scaled from 1e-21 (PSD in the denormals) to 1e18, streams sitting on
+    the domain's edges, and streams that jump between scales mid-way (the one-frame hand-over between the
+    two paths) must all be bit-identical to the oracle."""
+    import speech_enhancement_amd as sea
+    torch = _torch()
+    base = _float_stream_case(11)
+    cases = [base * np.float32(sc) for sc in (1.0, 1e-3, 3e-6, 1e-7, 3e-9, 1e-12, 1e-19, 1e-21, 30.0, 1e3, 1e5, 1e9, 1e18)]
+    mixed = _float_stream_case(12, 90)
+    mixed[20:35] *= np.float32(1e-9)
+    mixed[35:50] *= np.float32(1e7)
+    mixed[50:52] = 0.0
+    mixed[60:75] *= np.float32(1e-20)
+    cases.append(mixed)
+    cases.append(np.concatenate([base * np.float32(1e6), base, base * np.float32(2e-8)]))
+    for k, x in enumerate(cases):
+        want, wprod = oracle.ns_stream_f32(x)
+        o, p, _ = sea.ns_streams_push(torch.from_numpy(x[None]).cuda().contiguous())
+        p = p[0].cpu().numpy()
+        assert np.array_equal(p, wprod), f"case {k}: produced flags"
+        got = o[0].cpu().numpy()[p != 0].reshape(-1)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), \
+            f"case {k}: {np.count_nonzero(got.view(np.uint32) != want.view(np.uint32))} of {got.size} floats differ"
+
+
+def test_selftest_nsdiv_guarded_division():
+    """The NoiseSup back half divides with the compiler's own IEEE sequence minus v_div_scale / v_div_fixup
+    (identities inside the per-frame guarded operand domain) and one reciprocal per denominator: bit-equal
+    to plain division on 2^30 random + edge-mantissa pairs spanning that domain; same for the double
+    reciprocal in the second-stage noise update."""
+    import ctypes
+    import speech_enhancement_amd as sea
+    _torch()
+    out = (ctypes.c_ulonglong * 3)(0, 99, 99)
+    assert sea.load().sea_selftest_nsdiv(out) == 0
+    assert out[0] == 4096 * 256 * 1024
+    assert out[1] == 0 and out[2] == 0, f"{out[1]} float / {out[2]} double quotients differ of {out[0]}"
+
+
 def test_selftest_div_by_middle_ear_gain():
     """The resynthesis kernels divide by the per-channel middle-ear gain with q = a*y, r = a - q*d,
     q' = q + r*y (y = 1/d): exhaustively equal to the IEEE quotient for every float inside the
