@@ -488,9 +488,10 @@ __device__ __forceinline__ float ns_mel_fb(const BackLds &B, const NsConst &C, i
     if (lane < SEA_NMEL) {
 #pragma unroll
         for (int i = 0; i < SEA_MEL_TAPS; ++i) {
+            /* taps past the band's length carry weight 0 in the table: melOut + W * 0 == melOut exactly (W is
+             * a finite gain, melOut >= +0), which keeps a select out of the dependent chain */
             const int idx = C.melStart + i;
-            const float t = melOut + B.wbuf[idx < 65 ? idx : 64] * C.melW[i];
-            melOut = (i < C.melLen) ? t : melOut;
+            melOut = melOut + B.wbuf[idx < 65 ? idx : 64] * C.melW[i];
         }
     }
     return melOut;
@@ -821,48 +822,74 @@ __device__ __forceinline__ bool dc_filter(const float *dif, float *out, float &y
  * dependent vector instruction every 8 clk whatever the number of active lanes, so the three
  * 65..80-step chains cost 80 dependent FMAs instead of 225 dependent operations.  den[65..67] must be
  * zero (they are: the record is cleared once and only [0..64] is ever written); zero4: four zero
- * floats; junk: 160 floats of scratch for the partial sums of the two sum groups.  All three are always computed; the caller
- * discards what it does not need.  Ends with wave_sync(). */
+ * floats.  All three are always computed; the caller discards what it does not need.  Ends with wave_sync(). */
+template <int CHUNKS>
 __device__ __forceinline__ void helper_chains(const float *sq, const float *den, const float *dif, float *out,
-                                              float *junk, const float *zero4, float &vadSum, float &denSum,
+                                              const float *zero4, float &vadSum, float &denSum,
                                               float &y, int lane)
 {
     const int g = lane >> 4;
     const float *src = (g == 0) ? sq : ((g == 1) ? den : dif);
     const float *tail = (g == 1) ? zero4 : src; /* the den chain runs out after 65 terms: x = 0 from n = 68 on */
-    float *dst = (g == 0) ? junk : ((g == 1) ? junk + SEA_HOP : out);
     const float m = (g >= 2) ? 0.9990234375f : 1.0f;
     float acc = (g == 0) ? 64.0f : ((g == 1) ? 0.0f : y);
-    /* all 20 quads are requested before the chain starts (80 VGPRs, the helper wave has them to spare):
-     * an LDS round trip is ~60 clk, eight dependent-FMA slots */
-#ifndef SEA_CHAIN_CHUNKS
-#define SEA_CHAIN_CHUNKS 4 /* quads requested per group: 20 / 4 = 5 (20 VGPRs).  1 chunk (80 VGPRs) is ~1 % faster at four
-                              * workgroups per CU but caps the occupancy there; 4 chunks: 296 vs 267 M frames/s at 8192 utterances */
-#endif
-    constexpr int kQ = SEA_HOP / 4 / SEA_CHAIN_CHUNKS;
-#pragma unroll
-    for (int c = 0; c < SEA_CHAIN_CHUNKS; ++c) {
-        float4 x[kQ];
+    /* The 20 quads are requested in CHUNKS chunks (4: 2 x 20 VGPRs in flight; 10: 2 x 8, for the 80-VGPR kernel
+     * forms), chunk c + 1 before the chain of chunk c starts (an LDS round trip is ~60 clk = eight dependent-FMA
+     * slots).  Only the DC chain's partial results are wanted.  Storing them as they appear (a ds_write_b128 per
+     * four steps, whatever the number of active lanes) made a step cost 18 clk instead of the 8 of a dependent
+     * FMA; instead lane 32 + (n mod 32) of the DC group -- all of whose lanes hold the same value -- captures
+     * step n with a v_cndmask under a one-bit scalar mask (an independent instruction that issues in the shadow
+     * of the dependent FMA), and the captures leave as three ds_write_b32, one per 32 steps. */
+    constexpr int kQ = SEA_HOP / 4 / CHUNKS;
+    float4 x[2][kQ];
+    auto request = [&](int c, float4(&dstq)[kQ]) {
 #pragma unroll
         for (int k = 0; k < kQ; ++k) {
             const int n = 4 * (c * kQ + k);
-            x[k] = *reinterpret_cast<const float4 *>((n >= 68) ? tail + ((g == 1) ? 0 : n) : src + n);
+            dstq[k] = *reinterpret_cast<const float4 *>((n >= 68) ? tail + ((g == 1) ? 0 : n) : src + n);
         }
+    };
+    float cap = 0.0f;
+    unsigned long long bit = 0; /* the capture mask walks from lane 32 to lane 63 by one scalar shift per step (made
+                                 * opaque to the compiler, which would otherwise keep 80 constant masks in SGPRs) */
+    auto capture = [&](float v, int n) { /* step n's value into lane 32 + n % 32; stored every 32 steps */
+        if ((n & 31) == 0) {
+            asm("s_mov_b64 %0, 1" : "=s"(bit));
+            bit <<= 32;
+        } else
+            bit <<= 1;
+        asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(cap) : "v"(v), "s"(bit));
+        if ((n & 31) == 31 || n == SEA_HOP - 1) {
+            if (lane >= 32 && lane - 32 <= (n & 31)) out[(n & ~31) + lane - 32] = cap;
+        }
+    };
+    auto step = [&](float xv, int n) {
+        /* the capture of step n - 1 is issued AFTER the FMA of step n: it reads the FMA's input, so it does
+         * not wait for the FMA's result and the next FMA is not queued behind it */
+        float next; /* (volatile asm on both: the compiler would otherwise update acc in place, capture first) */
+        asm volatile("v_fma_f32 %0, %2, %1, %3" : "=&v"(next) : "v"(m), "v"(acc), "v"(xv));
+        if (n > 0) capture(acc, n - 1);
+        acc = next;
+    };
+    request(0, x[0]);
+#ifndef SEA_ABLATE_CHAIN
+#define SEA_ABLATE_CHAIN CHUNKS
+#endif
+#pragma unroll
+    for (int c = 0; c < SEA_ABLATE_CHAIN; ++c) {
+        if (c + 1 < CHUNKS) request(c + 1, x[(c + 1) & 1]);
 #pragma unroll
         for (int k = 0; k < kQ; ++k) {
-            float4 o;
-            acc = __fmaf_rn(m, acc, x[k].x);
-            o.x = acc;
-            acc = __fmaf_rn(m, acc, x[k].y);
-            o.y = acc;
-            acc = __fmaf_rn(m, acc, x[k].z);
-            o.z = acc;
-            acc = __fmaf_rn(m, acc, x[k].w);
-            o.w = acc;
-            *reinterpret_cast<float4 *>(dst + 4 * (c * kQ + k)) = o;
+            const float4 v = x[c & 1][k];
+            const int n = 4 * (c * kQ + k);
+            step(v.x, n);
+            step(v.y, n + 1);
+            step(v.z, n + 2);
+            step(v.w, n + 3);
         }
-        if (c + 1 < SEA_CHAIN_CHUNKS) __builtin_amdgcn_sched_barrier(0);
+        if (c + 1 < CHUNKS) __builtin_amdgcn_sched_barrier(0);
     }
+    if (SEA_ABLATE_CHAIN == CHUNKS) capture(acc, SEA_HOP - 1);
     vadSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
     denSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 16));
     y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 32));

@@ -58,7 +58,7 @@ struct __attribute__((aligned(16))) Pipe6Lds {
     float circ[2][kCirc + kMirror];
     float work[2][512];             /* transform work areas: FA fills [i & 1], FB finishes [(i-1) & 1] */
     BackLds back[2];                /* scratch of B0 and G1 */
-    float ssq[80], sdif[80], sout[80], sjunk[160], szero[4]; /* scratch of S */
+    float ssq[80], sdif[80], sout[80], szero[4]; /* scratch of S */
     float frameEn[kSlots], denSum[kSlots];
     int fdFlags[kSlots];
     float idctT[SEA_NMEL * 16];
@@ -349,7 +349,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a)
             if (doVad || doDen || produced) {
                 wave_sync();
                 float vadSum, denTotal, y = dcY;
-                helper_chains(L.ssq, denSrc, L.sdif, L.sout, L.sjunk, L.szero, vadSum, denTotal, y, lane);
+                helper_chains<10>(L.ssq, denSrc, L.sdif, L.sout, L.szero, vadSum, denTotal, y, lane);
                 if (doVad) {
                     const float en = vad_frame_energy(vadSum);
                     if (lane == 0) L.frameEn[(tp + 2) & (kSlots - 1)] = en;

@@ -116,7 +116,6 @@ struct __attribute__((aligned(16))) PipeLds {
     uint4 fftAddr[ADDR_LDS ? SEA_FFT_LSTAGES * 64 : 1]; /* F's butterfly operand addresses (Fft2Regs) */
     BackLds back[2];                /* scratch of B0 and B1 */
     float ssq[80], sdif[80], sout[80]; /* scratch of S */
-    float sjunk[160];               /* partial sums of S's two sum chains (never read) */
     float szero[4];                 /* zeros: what the shorter chain reads past its end */
     float sfir[80];                 /* second-stage filter output before the DC-offset filter */
     float frameEn[kSlots];          /* VAD log-energy for tick t at [t & 7] */
@@ -390,7 +389,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
             if (doVad || doDen || produced) {
                 wave_sync();
                 float vadSum, denTotal, y = dcY;
-                helper_chains(L.ssq, denSrc, L.sdif, L.sout, L.sjunk, L.szero, vadSum, denTotal, y, lane);
+                helper_chains<ADDR_LDS ? 10 : 4>(L.ssq, denSrc, L.sdif, L.sout, L.szero, vadSum, denTotal, y, lane);
                 NS_T_CK(1);
                 if (doVad) {
                     const float en = vad_frame_energy(vadSum);
