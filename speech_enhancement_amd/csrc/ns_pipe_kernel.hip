@@ -207,6 +207,27 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
         uint32_t nextw = (lane < 40 && nfr > 0) ? in32[lane] : 0u;
         int tick = 0; /* frames seen since (and including) the first non-zero one */
         int onset = (int)nfr;
+        /* The intake of a frame (zero-frame gate, int16 -> float, store into its slot of the stage-0 buffer)
+         * runs at the BOTTOM of the previous iteration, when its words (requested one iteration earlier still)
+         * have long arrived: the new slot is outside every window read during that iteration, and the
+         * transform's window loads at the top of the next one no longer wait for these LDS stores.
+         * (valid, tick) of frames i, i-1, i-2 stay in registers: B0 only copies them from Rec01 to Rec12. */
+        int vCur = 0, tCur = 0, v1 = 0, t1 = 0, v2 = 0, t2 = 0;
+        auto intake = [&](long long f) {
+            const uint32_t w = nextw;
+            if (f + 1 < nfr && lane < 40) nextw = in32[(f + 1) * 40 + lane];
+            const bool any = __ballot(w != 0u) != 0ull;
+            vCur = 0;
+            if (any || tick > 0) {
+                vCur = 1;
+                if (FD && tick == 0) onset = (int)f;
+                tick++;
+                const float x0 = (float)(short)(w & 0xFFFFu), x1 = (float)(short)(w >> 16);
+                if (lane < 40) slot_store(L.circ[0], tick, lane, x0, x1);
+            }
+            tCur = tick;
+        };
+        if (nfr > 0) intake(0);
         NS_T_CK_DECL;
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
@@ -215,46 +236,35 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
             bool actA = false;
             Rec01 &rA = L.r01[i & 1];
             if (i < nfr) {
-                const uint32_t w = nextw;
-                if (i + 1 < nfr && lane < 40) nextw = in32[(i + 1) * 40 + lane];
-                const bool any = __ballot(w != 0u) != 0ull;
-                int valid = 0;
-                if (any || tick > 0) {
-                    valid = 1;
-                    if (FD && tick == 0) onset = (int)i;
-                    tick++;
-                    const float x0 = (float)(short)(w & 0xFFFFu), x1 = (float)(short)(w >> 16);
-                    if (lane < 40) slot_store(L.circ[0], tick, lane, x0, x1);
-                    /* nbFramesInFirstStage - nbFramesInSecondStage > 2 (NoiseSup.c:1152) <=> tick >= 3 */
-                    actA = (SEA_ROLE_MASK & 1) && tick >= 3;
-                }
+                /* nbFramesInFirstStage - nbFramesInSecondStage > 2 (NoiseSup.c:1152) <=> tick >= 3 */
+                actA = (SEA_ROLE_MASK & 1) && vCur && tCur >= 3;
                 if (lane == 0) {
-                    rA.valid = valid;
-                    rA.tick = tick;
+                    rA.valid = vCur;
+                    rA.tick = tCur;
                 }
             }
             /* stage 1, frame i-2: nbFramesInSecondStage - nbFramesOut > 2 (NoiseSup.c:1178) <=> tick >= 5 */
             const long long fB = i - 2;
             bool actB = false;
-            int tB = 0;
+            const int tA = tCur, tB = t2;
             Rec23 &rB = L.r23[fB & 1];
             if (fB >= 0 && fB < nfr) {
-                const Rec12 &r = L.r12[fB & 1];
-                const int valid = r.valid;
-                tB = r.tick;
-                actB = (SEA_ROLE_MASK & 1) && valid && tB >= 5;
+                actB = (SEA_ROLE_MASK & 1) && v2 && tB >= 5;
                 if (lane == 0) {
-                    rB.valid = valid;
+                    rB.valid = v2;
                     rB.tick = tB;
                 }
             }
             NS_T_CK(5);
             if (actA || actB) {
                 wave_sync();
-                ns_front_dual<ADDR_LDS>(L.circ[0] + window_base(tick), actA, rA.psd, L.circ[1] + window_base(tB), actB, rB.psd,
+                ns_front_dual<ADDR_LDS>(L.circ[0] + window_base(tA), actA, rA.psd, L.circ[1] + window_base(tB), actB, rB.psd,
                               L.work, fft, flags, win, lane);
             }
             NS_T_CK(6);
+            v2 = v1, t2 = t1, v1 = vCur, t1 = tCur;
+            vCur = 0;
+            if (i + 1 < nfr) intake(i + 1);
             NS_T_MID;
             block_sync();
             NS_T_END;
