@@ -501,22 +501,36 @@ __device__ __forceinline__ float ns_mel_fb(const BackLds &B, const NsConst &C, i
  * the 17-tap FIR over buf[80..159] with 8 samples of context either side (NoiseSup.c:324-340);
  * lanes 0..39 produce two outputs each into dst.  Ends with wave_sync().
  * LDSBASIS: the 9x25 basis sits in LDS ([f][16], lane = row) instead of 25 VGPRs per lane. */
-template <bool LDSBASIS>
+template <bool LDSBASIS, bool RL = false>
 __device__ __forceinline__ void ns_idct_taps(float melOut, BackLds &B, const NsConst &C, int lane, const float *idctLds)
 {
-    if (lane < SEA_NMEL) B.mel[lane] = melOut;
-    wave_sync();
+    /* RL (the latency-bound kernel forms): band f's gain sits in lane f and reaches the nine row lanes through
+     * v_readlane (a scalar operand of the multiply) instead of an LDS store, a fence and seven broadcast reads.
+     * The issue-bound forms keep the LDS route: 25 lane reads are 25 more vector instructions. */
+    float mf[SEA_NMEL];
+    if (RL) {
+#pragma unroll
+        for (int f = 0; f < SEA_NMEL; ++f) mf[f] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(melOut), f));
+    } else {
+        if (lane < SEA_NMEL) B.mel[lane] = melOut;
+        wave_sync();
+    }
     if (lane <= 8) {
         float h = 0.0f;
+        if (RL) {
 #pragma unroll
-        for (int f4 = 0; f4 < 24; f4 += 4) {
-            const float4 m = *reinterpret_cast<const float4 *>(&B.mel[f4]);
-            h += m.x * (LDSBASIS ? idctLds[(f4 + 0) * 16 + lane] : C.idct[f4]);
-            h += m.y * (LDSBASIS ? idctLds[(f4 + 1) * 16 + lane] : C.idct[f4 + 1]);
-            h += m.z * (LDSBASIS ? idctLds[(f4 + 2) * 16 + lane] : C.idct[f4 + 2]);
-            h += m.w * (LDSBASIS ? idctLds[(f4 + 3) * 16 + lane] : C.idct[f4 + 3]);
+            for (int f = 0; f < SEA_NMEL; ++f) h += mf[f] * (LDSBASIS ? idctLds[f * 16 + lane] : C.idct[f]);
+        } else {
+#pragma unroll
+            for (int f4 = 0; f4 < 24; f4 += 4) {
+                const float4 m = *reinterpret_cast<const float4 *>(&B.mel[f4]);
+                h += m.x * (LDSBASIS ? idctLds[(f4 + 0) * 16 + lane] : C.idct[f4]);
+                h += m.y * (LDSBASIS ? idctLds[(f4 + 1) * 16 + lane] : C.idct[f4 + 1]);
+                h += m.z * (LDSBASIS ? idctLds[(f4 + 2) * 16 + lane] : C.idct[f4 + 2]);
+                h += m.w * (LDSBASIS ? idctLds[(f4 + 3) * 16 + lane] : C.idct[f4 + 3]);
+            }
+            h += B.mel[24] * (LDSBASIS ? idctLds[24 * 16 + lane] : C.idct[24]);
         }
-        h += B.mel[24] * (LDSBASIS ? idctLds[24 * 16 + lane] : C.idct[24]);
         const float tap = h * C.irWin;
         B.fir[8 + lane] = tap;
         B.fir[8 - lane] = tap;
@@ -560,11 +574,11 @@ __device__ __forceinline__ void ns_fir_apply(const float *fir, const float *buf,
     wave_sync();
 }
 
-template <bool LDSBASIS>
+template <bool LDSBASIS, bool RL = false>
 __device__ __forceinline__ void ns_idct_fir(float melOut, BackLds &B, const NsConst &C, const float *buf,
                                             float *dst, int lane, const float *idctLds)
 {
-    ns_idct_taps<LDSBASIS>(melOut, B, C, lane, idctLds);
+    ns_idct_taps<LDSBASIS, RL>(melOut, B, C, lane, idctLds);
     ns_fir_apply(B.fir, buf, dst, lane);
 }
 
@@ -578,7 +592,7 @@ __device__ __forceinline__ void ns_idct_fir(float melOut, BackLds &B, const NsCo
  *   ST 1: the caller has loaded s.denEn0..2.
  * DEFER_FIR: stop after the IDCT and deposit the 17 filter taps in dst[0..16]; the FIR itself is then
  *   run by the consumer wave (ns_fir_apply), which has cycles to spare. */
-template <int ST, bool PIPE, bool FD = false, bool DEFER_FIR = false>
+template <int ST, bool PIPE, bool FD = false, bool DEFER_FIR = false, bool RL = false>
 __device__ __forceinline__ void ns_back(const float *psd, const float *buf, BackLds &B, NsRegs &s,
                                         const NsConst &C, float *dst, int lane, float frameEnExt = 0.0f,
                                         float *spectOut = nullptr, const float *idctLds = nullptr,
@@ -624,12 +638,14 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
         WLo = filter_bin<ST>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
         WHi = filter_bin<ST>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
     }
-    float *spect = (PIPE && ST == 0) ? spectOut : B.sbuf;
     B.wbuf[lane] = WLo;
-    spect[lane] = (ST == 0) ? s.denLo[0] : s.noiseLo[1];
-    if (lane == 0) {
-        B.wbuf[64] = WHi;
-        spect[64] = (ST == 0) ? s.denHi[0] : s.noiseHi[1];
+    if (lane == 0) B.wbuf[64] = WHi;
+    if (PIPE && ST == 0) { /* the helper wave sums denSigSE1 */
+        spectOut[lane] = s.denLo[0];
+        if (lane == 0) spectOut[64] = s.denHi[0];
+    } else if (!RL) {
+        B.sbuf[lane] = (ST == 0) ? s.denLo[0] : s.noiseLo[1];
+        if (lane == 0) B.sbuf[64] = (ST == 0) ? s.denHi[0] : s.noiseHi[1];
     }
     wave_sync();
 
@@ -649,11 +665,24 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
 
     /* --- DoGainFact (NoiseSup.c:581-642) --- */
     if (!(PIPE && ST == 0)) {
-#ifdef SEA_ABLATE_GSUM
-        const float total = B.sbuf[0] + B.sbuf[64];
-#else
-        const float total = serial_sum<65>(B.sbuf, 0.0f);
-#endif
+        /* the in-order sum over bins 0..64 (NoiseSup.c:597-601).  RL (latency-bound kernel forms): the values sit
+         * one per lane and each term arrives through v_readlane as a scalar operand, no LDS staging (-230 clk
+         * per frame on the second-stage wave); the issue-bound forms read the staged copy back in quads */
+        float total = 0.0f;
+        if (RL) {
+            const float vHi = (ST == 0) ? s.denHi[0] : s.noiseHi[1];
+            float src = (ST == 0) ? s.denLo[0] : s.noiseLo[1];
+#pragma unroll
+            for (int k = 0; k < 64; ++k) {
+                /* (every 16 terms the source is made to depend on the running sum, or all 64 lane reads are
+                 * hoisted and their SGPRs spill) */
+                if (k > 0 && (k & 15) == 0) asm("" : "+v"(src) : "v"(total));
+                total += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), k));
+            }
+            total += vHi;
+        } else {
+            total = serial_sum<65>(B.sbuf, 0.0f);
+        }
         if (ST == 0) {
             s.denEn0 = s.denEn1;
             s.denEn1 = s.denEn2;
@@ -664,11 +693,11 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
         }
     }
     if (DEFER_FIR) { /* the consumer wave applies the filter (ns_fir_apply): hand over the 17 taps */
-        ns_idct_taps<PIPE>(melOut, B, C, lane, idctLds);
+        ns_idct_taps<PIPE, RL>(melOut, B, C, lane, idctLds);
         if (lane < SEA_NTAP) dst[lane] = B.fir[lane];
         wave_sync();
     } else {
-        ns_idct_fir<PIPE>(melOut, B, C, buf, dst, lane, idctLds);
+        ns_idct_fir<PIPE, RL>(melOut, B, C, buf, dst, lane, idctLds);
     }
 }
 
@@ -712,7 +741,16 @@ __device__ __forceinline__ float ns_noise1(const float *psd, float *Pout, float 
         noiseOut[64] = s.noiseHi[1];
     }
     wave_sync();
-    const float total = serial_sum<65>(noiseOut, 0.0f);
+    float total = 0.0f; /* in-order sum of the noise spectrum through lane reads (see ns_back) */
+    {
+        float src = s.noiseLo[1];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            if (k > 0 && (k & 15) == 0) asm("" : "+v"(src) : "v"(total));
+            total += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), k));
+        }
+        total += s.noiseHi[1];
+    }
     gain_fact_update(s, total);
     return s.alfaGF;
 }
@@ -741,7 +779,7 @@ __device__ __forceinline__ void ns_gain1(const float *psd, const float *P, const
     wave_sync();
     float melOut = ns_mel_fb(B, C, lane);
     melOut = (float)((double)(alfaGF * melOut) + (1.0 - (double)alfaGF) * 1.0);
-    ns_idct_fir<true>(melOut, B, C, buf, dst, lane, idctLds);
+    ns_idct_fir<true, true>(melOut, B, C, buf, dst, lane, idctLds);
 }
 
 /* One whole stage on the single-wave form: stage 0 deposits its 80 output samples in

@@ -237,7 +237,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a)
                 if (valid && t >= 3) {
                     float *tmp = L.back[0].sq;
                     int bits = 0;
-                    ns_back<0, true, FD>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
+                    ns_back<0, true, FD, false, true>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
                                          L.frameEn[t & (kSlots - 1)], o.den, L.idctT, &fd, &bits);
                     if (FD && lane == 0) L.fdFlags[t & (kSlots - 1)] = bits;
                     if (lane < 40) {

@@ -292,7 +292,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                 if ((SEA_ROLE_MASK & 2) && valid && t >= 3) {
                     float *tmp = L.back[0].sq; /* FIR output staged here, then stored with its mirror */
                     int bits = 0;
-                    ns_back<0, true, FD>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
+                    ns_back<0, true, FD, false, !ADDR_LDS>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
                                          L.frameEn[t & (kSlots - 1)], o.den, L.idctT, &fd, &bits);
                     if (FD && lane == 0) L.fdFlags[t & (kSlots - 1)] = bits;
                     if (lane < 40) {
@@ -329,7 +329,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                     s.denEn0 = L.denSum[(t - 2) & (kSlots - 1)];
                     s.denEn1 = L.denSum[(t - 1) & (kSlots - 1)];
                     s.denEn2 = L.denSum[t & (kSlots - 1)];
-                    ns_back<1, true, false, SEA_FIR_IN_S != 0>(r.psd, L.circ[1] + window_base(t), L.back[1], s, C,
+                    ns_back<1, true, false, SEA_FIR_IN_S != 0, !ADDR_LDS>(r.psd, L.circ[1] + window_base(t), L.back[1], s, C,
                                                                SEA_FIR_IN_S ? o.fir : o.out, lane, 0.0f, nullptr, L.idctT);
                     produced = 1;
                 }
