@@ -582,6 +582,20 @@ __device__ __forceinline__ void ns_idct_fir(float melOut, BackLds &B, const NsCo
     ns_fir_apply(B.fir, buf, dst, lane);
 }
 
+/* timing-only diagnostic (-DSEA_NS_TIMING -DSEA_NS_BACK_CK): shader clocks between checkpoints inside ns_back(),
+ * accumulated by lane 0 of workgroup 0 in g_back_ck[ST * 8 + k]; read / reset through sea_debug_ns_back_ck().
+ * Each checkpoint costs ~300 clk (s_memtime round trip), so the role totals of such a build are inflated. */
+#ifdef SEA_NS_TIMING
+__device__ unsigned long long g_back_ck[16];
+#endif
+#if defined(SEA_NS_TIMING) && defined(SEA_NS_BACK_CK)
+#define NS_BACK_CK_START unsigned long long bt_ = clock64()
+#define NS_BACK_CK(k) do { const unsigned long long c_ = clock64(); if (blockIdx.x == 0 && lane == 0) g_back_ck[ST * 8 + (k)] += c_ - bt_; bt_ = c_; } while (0)
+#else
+#define NS_BACK_CK_START
+#define NS_BACK_CK(k)
+#endif
+
 /* BACK half of a stage (ST = 0 first, 1 second): everything recursive.  Consumes psd[0..64] and
  * the stage buffer (raw frame buf[80..159] for the VAD, buf[72..167] for the FIR), updates the
  * per-utterance state and deposits the 80 filtered samples in dst.  Ends with wave_sync().
@@ -598,6 +612,7 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
                                         float *spectOut = nullptr, const float *idctLds = nullptr,
                                         NsFd *fd = nullptr, int *fdFlags = nullptr)
 {
+    NS_BACK_CK_START;
     const float nSigLo = psd[lane], nSigHi = psd[64];
 
     /* --- PSDMean over two frames (NoiseSup.c:289-303) --- */
@@ -631,6 +646,18 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     const bool fast = SEA_NS_FAST_DIV && psdOk && noiseOk && (s.psdOk[ST] != 0);
     s.psdOk[ST] = psdOk ? 1 : 0;
     float WLo, WHi;
+    auto lane_sum = [&](float vLo, float vHi) {
+        /* in-order sum over bins 0..64 of values that sit one per lane: each term arrives through v_readlane
+         * as a scalar operand, no LDS staging.  (Every 16 terms the source is made to depend on the running
+         * sum, or all 64 lane reads are hoisted and their SGPRs spill.) */
+        float total = 0.0f, src = vLo;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            if (k > 0 && (k & 15) == 0) asm("" : "+v"(src) : "v"(total));
+            total += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), k));
+        }
+        return total + vHi;
+    };
     if (fast) {
         WLo = filter_bin<ST, true>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
         WHi = filter_bin<ST, true>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
@@ -638,6 +665,7 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
         WLo = filter_bin<ST>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
         WHi = filter_bin<ST>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
     }
+    NS_BACK_CK(0); /* PSD mean, VAD update, FilterCalc of 65 bins */
     B.wbuf[lane] = WLo;
     if (lane == 0) B.wbuf[64] = WHi;
     if (PIPE && ST == 0) { /* the helper wave sums denSigSE1 */
@@ -652,7 +680,9 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     int fdBits = 0;
     if (FD && ST == 0) fdBits = fd_var(*fd, B.wbuf, nb16); /* NoiseSup.c:1255-1258, before DoMelFB */
 
+    NS_BACK_CK(1); /* gains staged in LDS */
     float melOut = ns_mel_fb(B, C, lane);
+    NS_BACK_CK(2); /* mel filter bank */
 
     if (FD && ST == 0) { /* NoiseSup.c:1268-1281, on the mel-filtered gains; VADNS :1359-1365 */
         if (lane < SEA_NMEL) B.mel[lane] = melOut;
@@ -665,24 +695,11 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
 
     /* --- DoGainFact (NoiseSup.c:581-642) --- */
     if (!(PIPE && ST == 0)) {
-        /* the in-order sum over bins 0..64 (NoiseSup.c:597-601).  RL (latency-bound kernel forms): the values sit
-         * one per lane and each term arrives through v_readlane as a scalar operand, no LDS staging (-230 clk
-         * per frame on the second-stage wave); the issue-bound forms read the staged copy back in quads */
-        float total = 0.0f;
-        if (RL) {
-            const float vHi = (ST == 0) ? s.denHi[0] : s.noiseHi[1];
-            float src = (ST == 0) ? s.denLo[0] : s.noiseLo[1];
-#pragma unroll
-            for (int k = 0; k < 64; ++k) {
-                /* (every 16 terms the source is made to depend on the running sum, or all 64 lane reads are
-                 * hoisted and their SGPRs spill) */
-                if (k > 0 && (k & 15) == 0) asm("" : "+v"(src) : "v"(total));
-                total += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), k));
-            }
-            total += vHi;
-        } else {
-            total = serial_sum<65>(B.sbuf, 0.0f);
-        }
+        /* the in-order sum over bins 0..64 (NoiseSup.c:597-601): through lane reads in the latency-bound
+         * kernel forms (RL: -230 clk per frame on the second-stage wave), from the staged LDS copy in quads in the
+         * issue-bound ones, where 64 lane reads are 64 more vector instructions */
+        const float total = RL ? lane_sum((ST == 0) ? s.denLo[0] : s.noiseLo[1], (ST == 0) ? s.denHi[0] : s.noiseHi[1])
+                               : serial_sum<65>(B.sbuf, 0.0f);
         if (ST == 0) {
             s.denEn0 = s.denEn1;
             s.denEn1 = s.denEn2;
@@ -692,6 +709,7 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
             melOut = (float)((double)(s.alfaGF * melOut) + (1.0 - (double)s.alfaGF) * 1.0);
         }
     }
+    NS_BACK_CK(3); /* in-order sum, gain factor */
     if (DEFER_FIR) { /* the consumer wave applies the filter (ns_fir_apply): hand over the 17 taps */
         ns_idct_taps<PIPE, RL>(melOut, B, C, lane, idctLds);
         if (lane < SEA_NTAP) dst[lane] = B.fir[lane];
@@ -699,6 +717,7 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     } else {
         ns_idct_fir<PIPE, RL>(melOut, B, C, buf, dst, lane, idctLds);
     }
+    NS_BACK_CK(4); /* IDCT taps (+ FIR unless deferred) */
 }
 
 /* ---- the second-stage BACK half cut in two (six-wave kernel, ns_pipe6_kernel.hip) -------------------

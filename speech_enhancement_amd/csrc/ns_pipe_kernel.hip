@@ -453,6 +453,14 @@ __global__ __launch_bounds__(256, SEA_NS_MIN_WAVES) void ns_denoise_pipe_fd_kern
 } // namespace sea
 
 #ifdef SEA_NS_TIMING
+extern "C" int sea_debug_ns_back_ck(unsigned long long *out16, int reset)
+{
+    if (reset) {
+        unsigned long long z[16] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(sea::g_back_ck), z, sizeof z);
+    }
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(sea::g_back_ck), 16 * sizeof(unsigned long long));
+}
 extern "C" int sea_debug_ns_timing(unsigned long long *out8)
 {
     return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(sea::g_ns_timing), 24 * sizeof(unsigned long long));

@@ -16,16 +16,22 @@ def main():
     lib = ctypes.CDLL(sea.LIB_PATH)
     for n in (256, 1024):
         batch = sea.PackedBatch.from_arrays([base] * n, dev)
-        for _ in range(2):
-            sea.ns_denoise_batch(batch)
+        sea.ns_denoise_batch(batch)
         torch.cuda.synchronize()
+        bk = (ctypes.c_ulonglong * 16)()
+        assert lib.sea_debug_ns_back_ck(bk, 1) == 0
+        sea.ns_denoise_batch(batch)
+        torch.cuda.synchronize()
+        assert lib.sea_debug_ns_back_ck(bk, 0) == 0
         t = (ctypes.c_ulonglong * 24)()
         assert lib.sea_debug_ns_timing(t) == 0
         fr = L // 80 + 4
         print(json.dumps({"n_utt": n, **{nm: {"work_cyc_per_frame": round(t[2 * i] / fr), "wait_cyc_per_frame": round(t[2 * i + 1] / fr)}
                                          for i, nm in enumerate(["F", "B0", "B1", "S"])},
                           "S_checkpoints_cyc_per_frame(prep,chains,energy,verify,store)": [round(t[8 + q] / fr) for q in range(5)],
-                          "F_checkpoints_cyc_per_frame(input+records,transforms+psd)": [round(t[16] / fr), round(t[17] / fr)]}), flush=True)
+                          "F_checkpoints_cyc_per_frame(input+records,transforms+psd)": [round(t[16] / fr), round(t[17] / fr)],
+                          "B0_checkpoints_cyc_per_frame(filter,stage,mel,sum+gainfact,idct+fir)": [round(bk[q] / fr) for q in range(5)],
+                          "B1_checkpoints_cyc_per_frame(filter,stage,mel,sum+gainfact,idct)": [round(bk[8 + q] / fr) for q in range(5)]}), flush=True)
 
 
 if __name__ == "__main__":
