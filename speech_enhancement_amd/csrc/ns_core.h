@@ -462,20 +462,33 @@ __device__ __forceinline__ void psd_from_fft2(const float *work, float *psd, con
 /* Two FRONT halves in one wave: frame A (stage buffer bufA) and frame B (bufB) are windowed,
  * transformed side by side (rfft256_dual) and reduced to their 65-bin PSDs.  actA / actB are
  * wave-uniform; an inactive side is fed zeros and its PSD is not written.  work: 512 floats. */
+/* the lane's eight windowed input elements for rfft256_head8: element n0 + 32 * bitrev3(j) of its transform's
+ * frame (lanes 0..31: bufA, 32..63: bufB; analysis window on buf[60..259], zero beyond element 199 -- literal
+ * zeros, as the reference pads, not products with a zero weight).  An inactive side is fed zeros. */
+__device__ __forceinline__ void ns_window8(const float *bufA, bool actA, const float *bufB, bool actB,
+                                           const float (&win8)[8], int lane, float (&e)[8])
+{
+    const int n0 = lane & 31;
+    const bool hiHalf = lane >= 32;
+    const float *buf = hiHalf ? bufB : bufA;
+    const bool act = hiHalf ? actB : actA;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        constexpr int kRev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+        const int idx = n0 + 32 * kRev3[j];
+        const float v = buf[60 + idx]; /* 60 + 255 < 320: always inside the stage buffer */
+        e[j] = (act && idx < SEA_WIN) ? v * win8[j] : 0.0f;
+    }
+}
+
 template <bool ADDR_LDS>
 __device__ __forceinline__ void ns_front_dual(const float *bufA, bool actA, float *psdA, const float *bufB,
                                               bool actB, float *psdB, float *work, const Fft2Regs &fft,
-                                              unsigned flags, const float (&win)[4], int lane)
+                                              const float (&win8)[8], int lane)
 {
-    float eA[4], eB[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int idx = 60 + lane + 64 * k;
-        const bool in = (k < 3) || (lane < 8);
-        eA[k] = (actA && in) ? bufA[idx] * win[k] : 0.0f;
-        eB[k] = (actB && in) ? bufB[idx] * win[k] : 0.0f;
-    }
-    rfft256_dual<ADDR_LDS>(eA, eB, work, fft, flags, lane);
+    float e[8];
+    ns_window8(bufA, actA, bufB, actB, win8, lane, e);
+    rfft256_dual<ADDR_LDS>(e, work, fft);
     if (actA) psd_from_fft2(work, psdA, fft, lane);
     if (actB) psd_from_fft2(work + 256, psdB, fft, lane);
     wave_sync();

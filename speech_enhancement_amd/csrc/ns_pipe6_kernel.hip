@@ -131,10 +131,9 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a)
         /* ---- FA: input + zero-frame gate (ParmInterface.c:244-251); first half of both transforms ---- */
         Fft2Regs fft;
         load_fft2_regs<false>(fft, &a.tables->fft, lane, nullptr);
-        const unsigned flags = a.tables->fft.fftFlags[lane];
-        float win[4];
+        float win8[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) win[k] = a.tables->win[k][lane];
+        for (int k = 0; k < 8; ++k) win8[k] = a.tables->win8[k][lane];
         const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in + off);
         uint32_t nextw = (lane < 40 && nfr > 0) ? in32[lane] : 0u;
         int tick = 0; /* frames seen since (and including) the first non-zero one */
@@ -174,16 +173,9 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a)
             }
             if (actA || actB) {
                 wave_sync();
-                float eA[4], eB[4];
-                const float *bufA = L.circ[0] + window_base(tick), *bufB = L.circ[1] + window_base(t1);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int idx = 60 + lane + 64 * k;
-                    const bool in = (k < 3) || (lane < 8);
-                    eA[k] = (actA && in) ? bufA[idx] * win[k] : 0.0f;
-                    eB[k] = (actB && in) ? bufB[idx] * win[k] : 0.0f;
-                }
-                rfft256_dual_lo<false>(eA, eB, L.work[i & 1], fft, flags, lane);
+                float e[8];
+                ns_window8(L.circ[0] + window_base(tick), actA, L.circ[1] + window_base(t1), actB, win8, lane, e);
+                rfft256_dual_lo<false>(e, L.work[i & 1], fft);
             }
             block_sync();
         }

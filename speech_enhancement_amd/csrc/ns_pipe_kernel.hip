@@ -199,10 +199,9 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
         Fft2Regs fft;
         load_fft2_regs<ADDR_LDS>(fft, &a.tables->fft, lane, L.fftAddr);
         wave_sync();
-        const unsigned flags = a.tables->fft.fftFlags[lane];
-        float win[4];
+        float win8[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) win[k] = a.tables->win[k][lane];
+        for (int k = 0; k < 8; ++k) win8[k] = a.tables->win8[k][lane];
         const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in + off);
         uint32_t nextw = (lane < 40 && nfr > 0) ? in32[lane] : 0u;
         int tick = 0; /* frames seen since (and including) the first non-zero one */
@@ -259,7 +258,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
             if (actA || actB) {
                 wave_sync();
                 ns_front_dual<ADDR_LDS>(L.circ[0] + window_base(tA), actA, rA.psd, L.circ[1] + window_base(tB), actB, rB.psd,
-                              L.work, fft, flags, win, lane);
+                              L.work, fft, win8, lane);
             }
             NS_T_CK(6);
             v2 = v1, t2 = t1, v1 = vCur, t1 = tCur;

@@ -338,6 +338,7 @@ struct Fft2Regs {
     float tw[SEA_FFT_LSTAGES][4];
     unsigned headA[2], psdA[2];        /* frame A: where this lane stores its head values / finds its PSD inputs */
     unsigned nyq;
+    unsigned head8Flags, head8[4];     /* the eight-positions-per-lane start (sea_tables.h fft8*), this lane's transform */
 };
 
 
@@ -349,7 +350,7 @@ __device__ __forceinline__ void load_fft2_regs(Fft2Regs &R, const sea_fft_tables
     const unsigned half = (unsigned)(lane >> 5) * 1024u; /* second transform: the next 256 words */
     const unsigned both = half | (half << 16);
 #pragma unroll
-    for (int s = 0; s < SEA_FFT_LSTAGES; ++s) {
+    for (int s = 1; s < SEA_FFT_LSTAGES; ++s) { /* level 0 (n2 = 8) runs on registers: rfft256_head8 */
         R.kind[s] = t->fft2Item[s][j] >> 16;
         if (ADDR_LDS)
             addrLds[s * 64 + lane] = make_uint4(t->fft2Addr[s][0][j] + both, t->fft2Addr[s][1][j] + both,
@@ -366,6 +367,9 @@ __device__ __forceinline__ void load_fft2_regs(Fft2Regs &R, const sea_fft_tables
     R.psdA[0] = t->fft2Psd[0][lane];
     R.psdA[1] = t->fft2Psd[1][lane];
     R.nyq = t->fft2Nyq;
+    R.head8Flags = t->fft8Flags[lane];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) R.head8[q] = t->fft8Addr[q][lane] + both;
 }
 
 template <int S, bool ADDR_LDS>
@@ -479,16 +483,63 @@ __device__ __forceinline__ void rfft256_head(float e0, float e1, float e2, float
 
 /* two transforms at once: eA / eB hold the lane's four (windowed) elements of frame A / B.
  * The transform is offered in two halves so that a pipelined kernel can run them in different
- * waves (one frame apart): _lo = register-resident start + levels n2 = 8, 16, 32; _hi = levels
+ * waves (one frame apart): _lo = register-resident start (up to n2 = 8) + levels n2 = 16, 32; _hi = levels
  * n2 = 64, 128, 256.  Both end with wave_sync(). */
-template <bool ADDR_LDS>
-__device__ __forceinline__ void rfft256_dual_lo(const float (&eA)[4], const float (&eB)[4], float *work,
-                                                const Fft2Regs &R, unsigned flags, int lane)
+/* The register-resident start of BOTH transforms: lane l holds in e[0..7] the (windowed) input elements
+ * n0 + 32 * bitrev3(j), n0 = l & 31, of its transform (l >> 5), i.e. the bit-reversed positions 8k..8k+7,
+ * k = bitrev5(n0).  The length-2 butterflies (rfft.c:82-96), the n2 = 4 level (:100-113, plain butterflies
+ * only) and the n2 = 8 level (:100-125, plain + pi/4 butterflies, no twiddles yet) touch nothing outside
+ * such a block, so all three run on registers, gated per block by the reference's is/id schedule
+ * (fft8Flags); the eight results go to their swizzled places in this lane's work area. */
+__device__ __forceinline__ void rfft256_head8(float (&e)[8], float *work, const Fft2Regs &R)
 {
-    rfft256_head(eA[0], eA[1], eA[2], eA[3], work, flags, R.headA);
-    rfft256_head(eB[0], eB[1], eB[2], eB[3], work + 256, flags, R.headA);
-    wave_sync();
-    fft2_level<0, ADDR_LDS>(work, R);
+    const unsigned fl = R.head8Flags;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float a = e[2 * p], b = e[2 * p + 1], sum = a + b, dif = a - b;
+        const bool f = (fl & (1u << p)) != 0;
+        e[2 * p] = f ? sum : a;
+        e[2 * p + 1] = f ? dif : b;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float g0 = e[4 * h], g2 = e[4 * h + 2], g3 = e[4 * h + 3];
+        const float t1 = g3 + g2;
+        const float n3 = g3 - g2, n2 = g0 - t1, n0 = g0 + t1;
+        const bool f = (fl & (16u << h)) != 0;
+        e[4 * h + 3] = f ? n3 : g3;
+        e[4 * h + 2] = f ? n2 : g2;
+        e[4 * h] = f ? n0 : g0;
+    }
+    {
+        /* a-quadruple = positions 8k + {0,2,4,6} (n4 = 2), b-quadruple = 8k + {1,3,5,7} (n8 = 1) */
+        const float x1 = e[0], x2 = e[2], x3 = e[4], x4 = e[6], x5 = e[1], x6 = e[3], x7 = e[5], x8 = e[7];
+        const float t1 = x4 + x3;
+        const float o4 = x4 - x3, o3 = x1 - t1, o1 = x1 + t1;
+        const float u1 = (float)((double)(x7 + x8) * 0.70710678118654752440);
+        const float u2 = (float)((double)(x7 - x8) * 0.70710678118654752440);
+        const float o8 = x6 - u1, o7 = -x6 - u1, o6 = x5 - u2, o5 = x5 + u2;
+        const bool f = (fl & 64u) != 0;
+        e[0] = f ? o1 : x1;
+        e[2] = x2;
+        e[4] = f ? o3 : x3;
+        e[6] = f ? o4 : x4;
+        e[1] = f ? o5 : x5;
+        e[3] = f ? o6 : x6;
+        e[5] = f ? o7 : x7;
+        e[7] = f ? o8 : x8;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        fft_at(work, R.head8[q] & 0xffffu) = e[2 * q];
+        fft_at(work, R.head8[q] >> 16) = e[2 * q + 1];
+    }
+}
+
+template <bool ADDR_LDS>
+__device__ __forceinline__ void rfft256_dual_lo(float (&e)[8], float *work, const Fft2Regs &R)
+{
+    rfft256_head8(e, work, R);
     wave_sync();
     fft2_level<1, ADDR_LDS>(work, R);
     wave_sync();
@@ -508,10 +559,9 @@ __device__ __forceinline__ void rfft256_dual_hi(float *work, const Fft2Regs &R)
 }
 
 template <bool ADDR_LDS>
-__device__ __forceinline__ void rfft256_dual(const float (&eA)[4], const float (&eB)[4], float *work,
-                                             const Fft2Regs &R, unsigned flags, int lane)
+__device__ __forceinline__ void rfft256_dual(float (&e)[8], float *work, const Fft2Regs &R)
 {
-    rfft256_dual_lo<ADDR_LDS>(eA, eB, work, R, flags, lane);
+    rfft256_dual_lo<ADDR_LDS>(e, work, R);
     rfft256_dual_hi<ADDR_LDS>(work, R);
 }
 

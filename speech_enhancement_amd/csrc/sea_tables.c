@@ -150,6 +150,22 @@ static void build_fft(sea_fft_tables *f)
         f->fft2Psd[1][lane] = (sea_fft_swizzle(255 - 2 * l) * 4u) | ((sea_fft_swizzle((256 - 2 * l) & 255u) * 4u) << 16);
     }
     f->fft2Nyq = sea_fft_swizzle(128) * 4u;
+    {   /* eight positions per lane: flags of the three register-resident stages and the store addresses */
+        mark_ctx len8;
+        memset(&len8, 0, sizeof len8);
+        for_each_block(SEA_NFFT, 8, 0, mark_visit, &len8);
+        for (lane = 0; lane < SEA_LANES; lane++) {
+            unsigned g = 8u * bitrev((unsigned)lane & 31u, 5), q, fl = 0;
+            for (q = 0; q < 4; q++) {
+                if (len2.mark[g + 2 * q]) fl |= 1u << q;
+                f->fft8Addr[q][lane] = (sea_fft_swizzle(g + 2 * q) * 4u) | ((sea_fft_swizzle(g + 2 * q + 1) * 4u) << 16);
+            }
+            if (len4.mark[g]) fl |= 16u;
+            if (len4.mark[g + 4]) fl |= 32u;
+            if (len8.mark[g]) fl |= 64u;
+            f->fft8Flags[lane] = fl;
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -277,6 +293,11 @@ void sea_build_ns_tables(sea_ns_tables *t)
         for (k = 0; k < 4; k++) {
             int i = lane + 64 * k;
             t->win[k][lane] = (i < SEA_WIN) ? hanning(i, SEA_WIN) : 0.0f;
+        }
+    for (lane = 0; lane < SEA_LANES; lane++)
+        for (k = 0; k < 8; k++) {
+            int i = (lane & 31) + 32 * (int)bitrev((unsigned)k, 3);
+            t->win8[k][lane] = (i < SEA_WIN) ? hanning(i, SEA_WIN) : 0.0f;
         }
     for (f = 0; f < SEA_NMEL; f++) {
         if (B[f].len > SEA_MEL_TAPS) abort();

@@ -62,6 +62,15 @@ typedef struct {
     unsigned fft2Psd[2][SEA_LANES];
     unsigned fft2Nyq;
     unsigned fft2Pad[3];
+    /* The dual transform's register-resident start: lane l (n0 = l & 31, transform l >> 5) owns the EIGHT
+     * positions 8k..8k+7, k = bitrev5(n0), which receive input elements n0 + 32 * bitrev3(j), j = 0..7
+     * (fft8Src[j] = 32 * bitrev3(j)), so that the length-2, n2 = 4 AND n2 = 8 butterflies all run on
+     * registers: one LDS round trip fewer than the four-per-lane head + level n2 = 8.
+     *   fft8Flags[l]    bits 0..3: length-2 butterfly on (8k+2p, 8k+2p+1); bits 4,5: n2 = 4 plain butterfly on
+     *                   8k..8k+3 / 8k+4..8k+7; bit 6: n2 = 8 plain + pi/4 butterflies on the block
+     *   fft8Addr[q][l]  swizzled byte offsets of positions 8k+2q, 8k+2q+1 (low | high << 16) */
+    unsigned fft8Flags[SEA_LANES];
+    unsigned fft8Addr[4][SEA_LANES];
 } sea_fft_tables;
 
 /* word index of element i (0..255) in the swizzled work area */
@@ -76,6 +85,7 @@ enum { SEA_BF_PAIR = 4 };
 typedef struct {
     sea_fft_tables fft;
     float win[4][SEA_LANES];                      /* Hanning(200)[l+64k], 0 beyond 199 */
+    float win8[8][SEA_LANES];                     /* Hanning(200)[(l & 31) + 32 * bitrev3(j)], 0 beyond 199: the dual head's layout */
     int melStart[SEA_LANES], melLen[SEA_LANES];   /* lanes 0..24 */
     float melW[SEA_MEL_TAPS][SEA_LANES];
     float idct[SEA_NMEL][SEA_LANES];              /* idct[f][t], lanes t = 0..8 */
