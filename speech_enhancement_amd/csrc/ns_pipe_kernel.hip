@@ -57,6 +57,7 @@ constexpr int kPipeWaves = 4;
  * working / waiting at the frame barrier -> g_ns_timing[role*2 + {0,1}] */
 #ifdef SEA_NS_TIMING
 __device__ unsigned long long g_ns_timing[24]; /* [8..15]: checkpoints inside S */
+__device__ unsigned g_ns_wg[4096 * 4];           /* per workgroup: frame-loop span in 10 ns ticks, HW_ID, XCC_ID, start tick (low 32 bits) */
 struct RoleTimer {
     unsigned long long work = 0, wait = 0, t0 = 0, t1 = 0;
     __device__ __forceinline__ void begin() { t0 = clock64(); }
@@ -228,6 +229,9 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
         };
         if (nfr > 0) intake(0);
         NS_T_CK_DECL;
+#ifdef SEA_NS_TIMING
+        const unsigned long long clk0_ = clock64(), wall0_ = wall_clock64();
+#endif
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
             NS_T_CK_START;
@@ -271,7 +275,19 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
         if (FD && a.onset_out && lane == 0) a.onset_out[u] = onset;
         NS_T_FLUSH(0);
 #ifdef SEA_NS_TIMING
-        if (blockIdx.x == 0 && lane == 0) { g_ns_timing[16] = ck_[5]; g_ns_timing[17] = ck_[6]; }
+        if (blockIdx.x < 4096 && lane == 0) {
+            const unsigned long long w1_ = wall_clock64();
+            g_ns_wg[blockIdx.x * 4 + 0] = (unsigned)(w1_ - wall0_);
+            g_ns_wg[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            g_ns_wg[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+            g_ns_wg[blockIdx.x * 4 + 3] = (unsigned)wall0_;
+        }
+        if (blockIdx.x == 0 && lane == 0) {
+            g_ns_timing[16] = ck_[5];
+            g_ns_timing[17] = ck_[6];
+            g_ns_timing[18] = clock64() - clk0_;        /* shader clocks over the whole frame loop ... */
+            g_ns_timing[19] = wall_clock64() - wall0_;  /* ... and the same span on the constant 100 MHz counter */
+        }
 #endif
     } else if (role == 1) {
         /* ---- B0: BACK of stage 0; its 80 outputs enter the stage-1 buffer ---- */
@@ -459,6 +475,10 @@ extern "C" int sea_debug_ns_back_ck(unsigned long long *out16, int reset)
         return (int)hipMemcpyToSymbol(HIP_SYMBOL(sea::g_back_ck), z, sizeof z);
     }
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(sea::g_back_ck), 16 * sizeof(unsigned long long));
+}
+extern "C" int sea_debug_ns_wg(unsigned *out, int n_wg)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sea::g_ns_wg), (size_t)n_wg * 4 * sizeof(unsigned));
 }
 extern "C" int sea_debug_ns_timing(unsigned long long *out8)
 {

@@ -14,7 +14,7 @@ def main():
     L = 48000
     base = corpus.synth_utterance(3, L)
     lib = ctypes.CDLL(sea.LIB_PATH)
-    for n in (256, 1024):
+    for n in (256, 512, 1024):
         batch = sea.PackedBatch.from_arrays([base] * n, dev)
         sea.ns_denoise_batch(batch)
         torch.cuda.synchronize()
@@ -30,6 +30,8 @@ def main():
                                          for i, nm in enumerate(["F", "B0", "B1", "S"])},
                           "S_checkpoints_cyc_per_frame(prep,chains,energy,verify,store)": [round(t[8 + q] / fr) for q in range(5)],
                           "F_checkpoints_cyc_per_frame(input+records,transforms+psd)": [round(t[16] / fr), round(t[17] / fr)],
+                          "shader_clock_MHz_during_the_launch": round(100.0 * t[18] / max(t[19], 1)),
+                          "frame_period_ns": round(t[19] * 10.0 / fr),
                           "B0_checkpoints_cyc_per_frame(filter,stage,mel,sum+gainfact,idct+fir)": [round(bk[q] / fr) for q in range(5)],
                           "B1_checkpoints_cyc_per_frame(filter,stage,mel,sum+gainfact,idct)": [round(bk[8 + q] / fr) for q in range(5)]}), flush=True)
 
