@@ -888,11 +888,17 @@ __device__ __forceinline__ bool dc_filter(const float *dif, float *out, float &y
  * (den[0..64]) and the DC-offset recurrence (dif[0..79] -> out[0..79], float-FMA form of dc_filter) --
  * advanced by ONE instruction stream, each in its own group of lanes: every step is
  *     acc = fma(m, acc, x[n])      m = 1 for the sums (RN(1*acc + x) == RN(acc + x)), 1023/1024 for DC
- * with per-lane source / destination pointers (lanes 0-15 | 16-31 | 32-63).  A wave64 issues a
- * dependent vector instruction every 8 clk whatever the number of active lanes, so the three
- * 65..80-step chains cost 80 dependent FMAs instead of 225 dependent operations.  den[65..67] must be
- * zero (they are: the record is cleared once and only [0..64] is ever written); zero4: four zero
- * floats.  All three are always computed; the caller discards what it does not need.  Ends with wave_sync(). */
+ * with per-lane source pointers (lanes 0-15 | 16-31 | 32-63).  A wave64 issues an instruction that depends on
+ * the one before it every ~10 clk whatever the number of active lanes, so the three 65..80-step chains cost 80
+ * dependent FMAs instead of 225 dependent operations.  den[65..67] must be zero (they are: the record is
+ * cleared once and only [0..64] is ever written); zero4: four zero floats.  All three are always computed; the
+ * caller discards what it does not need.  Ends with wave_sync().
+ *
+ * The 80 intermediate values of the DC chain are needed too (they are the output samples).  Anything issued
+ * between two FMAs of the chain costs its full issue time (tools/fma_probe.hip: FMA + one independent
+ * instruction = 14 clk per step, FMA alone 10), so the serial pass keeps only every fifth value -- lane 32 + j
+ * captures y[5j - 1], the value segment j starts from, under a one-bit scalar mask -- and lanes 32..47 then
+ * recompute their five outputs each, in parallel, with the same FMA on the same operands. */
 template <int CHUNKS>
 __device__ __forceinline__ void helper_chains(const float *sq, const float *den, const float *dif, float *out,
                                               const float *zero4, float &vadSum, float &denSum,
@@ -903,14 +909,10 @@ __device__ __forceinline__ void helper_chains(const float *sq, const float *den,
     const float *tail = (g == 1) ? zero4 : src; /* the den chain runs out after 65 terms: x = 0 from n = 68 on */
     const float m = (g >= 2) ? 0.9990234375f : 1.0f;
     float acc = (g == 0) ? 64.0f : ((g == 1) ? 0.0f : y);
-    /* The 20 quads are requested in CHUNKS chunks (4: 2 x 20 VGPRs in flight; 10: 2 x 8, for the 80-VGPR kernel
-     * forms), chunk c + 1 before the chain of chunk c starts (an LDS round trip is ~60 clk = eight dependent-FMA
-     * slots).  Only the DC chain's partial results are wanted.  Storing them as they appear (a ds_write_b128 per
-     * four steps, whatever the number of active lanes) made a step cost 18 clk instead of the 8 of a dependent
-     * FMA; instead lane 32 + (n mod 32) of the DC group -- all of whose lanes hold the same value -- captures
-     * step n with a v_cndmask under a one-bit scalar mask (an independent instruction that issues in the shadow
-     * of the dependent FMA), and the captures leave as three ds_write_b32, one per 32 steps. */
+    /* the 20 quads are requested in CHUNKS chunks (4: 2 x 20 VGPRs in flight; 10: 2 x 8, for the 80-VGPR kernel
+     * forms), chunk c + 1 before the chain of chunk c starts (an LDS round trip is ~60 clk) */
     constexpr int kQ = SEA_HOP / 4 / CHUNKS;
+    constexpr int kSeg = 5; /* 16 segments of 5 steps */
     float4 x[2][kQ];
     auto request = [&](int c, float4(&dstq)[kQ]) {
 #pragma unroll
@@ -919,34 +921,24 @@ __device__ __forceinline__ void helper_chains(const float *sq, const float *den,
             dstq[k] = *reinterpret_cast<const float4 *>((n >= 68) ? tail + ((g == 1) ? 0 : n) : src + n);
         }
     };
-    float cap = 0.0f;
-    unsigned long long bit = 0; /* the capture mask walks from lane 32 to lane 63 by one scalar shift per step (made
-                                 * opaque to the compiler, which would otherwise keep 80 constant masks in SGPRs) */
-    auto capture = [&](float v, int n) { /* step n's value into lane 32 + n % 32; stored every 32 steps */
-        if ((n & 31) == 0) {
-            asm("s_mov_b64 %0, 1" : "=s"(bit));
-            bit <<= 32;
-        } else
-            bit <<= 1;
-        asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(cap) : "v"(v), "s"(bit));
-        if ((n & 31) == 31 || n == SEA_HOP - 1) {
-            if (lane >= 32 && lane - 32 <= (n & 31)) out[(n & ~31) + lane - 32] = cap;
-        }
-    };
+    /* the segment inputs of the recomputing lanes (stride 5 floats across 16 lanes: 16 different banks) */
+    const int seg = (lane - 32) & 15;
+    float d5[kSeg];
+#pragma unroll
+    for (int k = 0; k < kSeg; ++k) d5[k] = dif[kSeg * seg + k];
+    float cap = y; /* lane 32 (segment 0) starts from the incoming state */
     auto step = [&](float xv, int n) {
-        /* the capture of step n - 1 is issued AFTER the FMA of step n: it reads the FMA's input, so it does
-         * not wait for the FMA's result and the next FMA is not queued behind it */
-        float next; /* (volatile asm on both: the compiler would otherwise update acc in place, capture first) */
+        float next; /* volatile asm keeps FMA n ahead of the capture of y[n - 1], which reads the FMA's input */
         asm volatile("v_fma_f32 %0, %2, %1, %3" : "=&v"(next) : "v"(m), "v"(acc), "v"(xv));
-        if (n > 0) capture(acc, n - 1);
+        if (n > 0 && n % kSeg == 0) {
+            const unsigned long long bit = 1ull << (32 + n / kSeg);
+            asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(cap) : "v"(acc), "s"(bit));
+        }
         acc = next;
     };
     request(0, x[0]);
-#ifndef SEA_ABLATE_CHAIN
-#define SEA_ABLATE_CHAIN CHUNKS
-#endif
 #pragma unroll
-    for (int c = 0; c < SEA_ABLATE_CHAIN; ++c) {
+    for (int c = 0; c < CHUNKS; ++c) {
         if (c + 1 < CHUNKS) request(c + 1, x[(c + 1) & 1]);
 #pragma unroll
         for (int k = 0; k < kQ; ++k) {
@@ -959,7 +951,15 @@ __device__ __forceinline__ void helper_chains(const float *sq, const float *den,
         }
         if (c + 1 < CHUNKS) __builtin_amdgcn_sched_barrier(0);
     }
-    if (SEA_ABLATE_CHAIN == CHUNKS) capture(acc, SEA_HOP - 1);
+    /* sixteen lanes redo their five steps from the captured start values */
+    {
+        float v = cap;
+#pragma unroll
+        for (int k = 0; k < kSeg; ++k) {
+            v = __fmaf_rn(0.9990234375f, v, d5[k]);
+            if (lane >= 32 && lane < 48) out[kSeg * seg + k] = v;
+        }
+    }
     vadSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
     denSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 16));
     y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 32));

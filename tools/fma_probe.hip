@@ -22,6 +22,9 @@ PROBE(k_fma_src0, asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(e), "v
 PROBE(k_fma_src1, asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(a) : "v"(e), "v"(b));)
 PROBE(k_fma_src2, asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a) : "v"(e), "v"(b));)
 PROBE(k_fma_capture, asm volatile("v_fma_f32 %0, %3, %0, %4\n s_lshl_b64 %2, %2, 1\n v_cndmask_b32_e64 %1, %1, %0, %2" : "+v"(a), "+v"(c), "+s"(msk) : "v"(e), "v"(b));)
+PROBE(k_fma_indep_mov, asm volatile("v_fma_f32 %0, %2, %0, %3\n v_mov_b32 %1, %3" : "+v"(a), "+v"(c) : "v"(e), "v"(b));)
+PROBE(k_fma_indep_cnd, asm volatile("v_fma_f32 %0, %3, %0, %4\n v_cndmask_b32_e64 %1, %1, %4, %2" : "+v"(a), "+v"(c), "+s"(msk) : "v"(e), "v"(b));)
+PROBE(k_fma_prevcap, asm volatile("v_fma_f32 %1, %4, %0, %5\n v_cndmask_b32_e64 %2, %2, %0, %3\n s_lshl_b64 %3, %3, 1\n v_fma_f32 %0, %4, %1, %5\n v_cndmask_b32_e64 %2, %2, %1, %3\n s_lshl_b64 %3, %3, 1" : "+v"(a), "+v"(b), "+v"(c), "+s"(msk) : "v"(e), "v"(e));)
 PROBE(k_mul_dep, asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a) : "v"(e));)
 template <typename K> void run(const char *name, K k)
 {
@@ -37,6 +40,6 @@ template <typename K> void run(const char *name, K k)
 int main()
 {
     run("k_add_dep", k_add_dep); run("k_mul_dep", k_mul_dep); run("k_fma_src0", k_fma_src0); run("k_fma_src1", k_fma_src1);
-    run("k_fma_src2", k_fma_src2); run("k_fma_capture", k_fma_capture);
+    run("k_fma_src2", k_fma_src2); run("k_fma_capture", k_fma_capture); run("k_fma_indep_mov", k_fma_indep_mov); run("k_fma_indep_cnd", k_fma_indep_cnd); run("k_fma_prevcap(2 steps)", k_fma_prevcap);
     return 0;
 }
