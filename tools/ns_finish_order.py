@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""tools/ns_finish_order.py -- which workgroups of the configs[1] launch finish last, and the per-frame time of
+each launch row (= priority level on its CU).  Needs the -DSEA_NS_TIMING variant (SEA_MI355X_LIB=ablate/libsea_<name>.so)."""
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import torch, bench
+import speech_enhancement_amd as sea
+dev = torch.device("cuda", 0)
+batch = bench.build_shard(1024, 0, dev)
+lib = ctypes.CDLL(sea.LIB_PATH)
+for _ in range(3): sea.ns_denoise_batch(batch)
+torch.cuda.synchronize()
+n = 1024
+buf = (ctypes.c_uint * (4 * n))()
+assert lib.sea_debug_ns_wg(buf, n) == 0
+a = np.frombuffer(buf, dtype=np.uint32).reshape(n, 4)
+order = batch.order.cpu().numpy()
+frames = np.asarray(batch.host_lengths)[order] // 80
+start = (a[:, 3] - a[:, 3].min()).astype(np.int64) & 0xffffffff
+end = (start + a[:, 0]) * 10e-3   # us
+span = a[:, 0] * 10.0 / np.maximum(frames, 1)
+idx = np.argsort(-end)[:12]
+print("last finishers: block, frames, ns/frame, end_us")
+for b in idx: print(int(b), int(frames[b]), round(float(span[b])), round(float(end[b]), 1))
+print("block 0..5:", [(int(frames[b]), round(float(span[b])), round(float(end[b]),1)) for b in range(6)])
+for lo, hi in ((0,256),(256,512),(512,768),(768,1024)):
+    print("row", lo//256, "median ns/frame", round(float(np.median(span[lo:hi]))), "max end_us", round(float(end[lo:hi].max()),1))
