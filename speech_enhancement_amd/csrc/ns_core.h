@@ -50,6 +50,9 @@ struct NsConst {
 };
 
 /* per-utterance recursive state that is not in LDS */
+#ifndef SEA_NS_PAIR_BINS
+#define SEA_NS_PAIR_BINS 1
+#endif
 #ifndef SEA_NS_FAST_DIV
 #define SEA_NS_FAST_DIV 1
 #endif
@@ -245,6 +248,76 @@ __device__ __forceinline__ float gain_bin(float Psqrt, float nSigSqrt, float noi
 }
 
 /* the whole bin: P = 2-frame mean PSD, nSig = this frame's PSD */
+/* ---- bins (lane, 64) as register pairs -------------------------------------------------------------------
+ * Bin 64 is computed by every lane (one value for the whole wave), which used to repeat the whole per-bin
+ * instruction sequence.  Inside the fast-division domain the gain computation is straight-line mul / add / fma
+ * code, so the pair (bin lane, bin 64) goes through it as one two-component vector: v_pk_mul_f32 / v_pk_add_f32 /
+ * v_pk_fma_f32 round each half exactly like the scalar instruction.  Only the reciprocals, the two selects and
+ * the square roots stay per component. */
+typedef float ns_v2f __attribute__((ext_vector_type(2)));
+struct NsRcp2 {
+    ns_v2f d, r;
+};
+__device__ __forceinline__ ns_v2f ns_fma2(ns_v2f a, ns_v2f b, ns_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ NsRcp2 ns_rcp2(ns_v2f d)
+{
+    const ns_v2f r0 = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const ns_v2f e = ns_fma2(-d, r0, ns_v2f{1.0f, 1.0f});
+    return NsRcp2{d, ns_fma2(e, r0, r0)};
+}
+__device__ __forceinline__ ns_v2f ns_div2(ns_v2f n, const NsRcp2 &R)
+{
+    ns_v2f q = n * R.r;
+    ns_v2f e = ns_fma2(-R.d, q, n);
+    q = ns_fma2(e, R.r, q);
+    e = ns_fma2(-R.d, q, n);
+    return ns_fma2(e, R.r, q);
+}
+/* gain_bin<true> on the pair; same operations in the same order per component */
+__device__ __forceinline__ ns_v2f gain_bin2(ns_v2f Psqrt, ns_v2f nSigSqrt, ns_v2f noise, ns_v2f &den)
+{
+    const float beta = (float)0.98, rsbMin = (float)0.079432823;
+    const NsRcp2 rn = ns_rcp2(noise);
+    const ns_v2f post = ns_div2(Psqrt, rn) - 1;
+    const ns_v2f postc = {(0 > post.x) ? 0 : post.x, (0 > post.y) ? 0 : post.y};
+    ns_v2f prio = beta * ns_div2(den, rn) + (1 - beta) * postc;
+    ns_v2f W = ns_div2(prio, ns_rcp2(1 + prio));
+    prio = ns_div2(W * Psqrt, rn);
+    prio = ns_v2f{(prio.x > rsbMin) ? prio.x : rsbMin, (prio.y > rsbMin) ? prio.y : rsbMin};
+    W = ns_div2(prio, ns_rcp2(1 + prio));
+    den = W * nSigSqrt;
+    return W;
+}
+
+/* filter_bin<ST, true> for the bins (lane, 64) together: noise tracking and square roots per component exactly
+ * as filter_bin does them, the gain computation on the pair */
+template <int ST>
+__device__ __forceinline__ void filter_bins_fast(float PLo, float PHi, float nSigLo, float nSigHi, float &noiseLo,
+                                                 float &noiseHi, float &denLo, float &denHi, int nb, int flagVAD,
+                                                 float eps, float &WLo, float &WHi)
+{
+    if (ST == 1) { /* (packing the two quotients of the noise update as well measured no gain) */
+        noise_track1<true>(PLo, noiseLo, nb, eps);
+        noise_track1<true>(PHi, noiseHi, nb, eps);
+    }
+    const ns_v2f nSig = {sqrtf(nSigLo), sqrtf(nSigHi)};
+    const ns_v2f P = {sqrtf(PLo), sqrtf(PHi)};
+    if (ST == 0) { /* VAD-gated noise tracking in magnitude, :531-546 */
+        const float lambda = (nb < 100) ? 1 - 1 / (float)nb : (float)0.99;
+        if (flagVAD == 0) {
+            const float nl = lambda * noiseLo + (1 - lambda) * P.x, nh = lambda * noiseHi + (1 - lambda) * P.y;
+            noiseLo = (nl < eps) ? eps : nl;
+            noiseHi = (nh < eps) ? eps : nh;
+        }
+    }
+    ns_v2f den = {denLo, denHi};
+    const ns_v2f W = gain_bin2(P, nSig, ns_v2f{noiseLo, noiseHi}, den);
+    denLo = den.x;
+    denHi = den.y;
+    WLo = W.x;
+    WHi = W.y;
+}
+
 template <int ST, bool FAST = false>
 __device__ __forceinline__ float filter_bin(float P, float nSig, float &noise, float &den, int nb,
                                             int flagVAD, float eps)
@@ -672,8 +745,13 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
         return total + vHi;
     };
     if (fast) {
-        WLo = filter_bin<ST, true>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
-        WHi = filter_bin<ST, true>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
+        if (SEA_NS_PAIR_BINS && RL) { /* not in the 80-VGPR form: the pairs cost registers there (9 spills, -4 %) */
+            filter_bins_fast<ST>(PLo, PHi, nSigLo, nSigHi, s.noiseLo[ST], s.noiseHi[ST], s.denLo[ST], s.denHi[ST],
+                                 nb16, s.flagVAD, C.eps, WLo, WHi);
+        } else {
+            WLo = filter_bin<ST, true>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
+            WHi = filter_bin<ST, true>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
+        }
     } else {
         WLo = filter_bin<ST>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
         WHi = filter_bin<ST>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
