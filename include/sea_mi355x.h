@@ -185,8 +185,10 @@ int sea_selftest_div(unsigned long long *out2);
 /* the NoiseSup gain / noise-tracking divisions inside their per-frame guarded domain (csrc/ns_core.h, ns_div:
  * the compiler's IEEE sequence without v_div_scale / v_div_fixup, reciprocal shared per denominator) against
  * plain division on 2^30 pseudo-random + edge-mantissa operand pairs spanning the domain, and the double
- * reciprocal of the noise update.  out3[0] = pairs tested, out3[1] = float mismatches, out3[2] = double */
-int sea_selftest_nsdiv(unsigned long long *out3);
+ * reciprocal of the noise update.  out4[0] = pairs tested, out4[1] = float mismatches, out4[2] = double;
+ * out4[3] = mismatches of the lean correctly rounded square root used in the same domain (ns_sqrt_fast: the
+ * sqrtf expansion without its tiny-argument scaling) against sqrtf over EVERY float in [2^-96, 2^126] and 0 */
+int sea_selftest_nsdiv(unsigned long long *out4);
 /* DC-offset recurrence on ncases frames of 80 differences (host pointers): output and whether the
  * exact double path had to be taken */
 int sea_selftest_dc(const float *dif, const float *y0, float *out, int *fellback, int ncases);

@@ -788,17 +788,17 @@ int sea_selftest_div(unsigned long long *out2)
     return 0;
 }
 
-int sea_selftest_nsdiv(unsigned long long *out3)
+int sea_selftest_nsdiv(unsigned long long *out4)
 {
     DeviceCtx *c;
     if (ctx(&c)) return 1;
     DevBuf<unsigned long long> d;
-    HIP_TRY(d.alloc(3));
-    HIP_TRY(hipMemset(d.p, 0, 3 * sizeof(unsigned long long)));
+    HIP_TRY(d.alloc(4));
+    HIP_TRY(hipMemset(d.p, 0, 4 * sizeof(unsigned long long)));
     hipLaunchKernelGGL(sea::selftest_nsdiv_kernel, dim3(4096), dim3(256), 0, nullptr, d.p, 1024);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out3, d.p, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out4, d.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -50,6 +50,14 @@ struct NsConst {
 };
 
 /* per-utterance recursive state that is not in LDS */
+#ifndef SEA_NS_FAST_SQRT
+#define SEA_NS_FAST_SQRT 1
+#endif
+#if SEA_NS_FAST_SQRT
+#define SEA_SQRT(x) ns_sqrt_fast(x)
+#else
+#define SEA_SQRT(x) sqrtf(x)
+#endif
 #ifndef SEA_NS_PAIR_BINS
 #define SEA_NS_PAIR_BINS 1
 #endif
@@ -149,6 +157,21 @@ __device__ __forceinline__ double ns_ln(double x)
  * (SURVEY F9).
  *
  * Second-stage noise tracking in the energy domain (:486-517): P = 2-frame mean PSD. */
+/* Correctly rounded square root for x = 0 or x in [2^-96, 2^126]: the compiler's sqrtf expansion (v_sqrt_f32, then the
+ * neighbours one ulp below / above tested with an exact fma residual) without its input scaling for tiny
+ * arguments and its zero / infinity fix-up, which do nothing on this range (x = 0: v_sqrt gives 0 and neither
+ * neighbour is selected).  9 instead of 15 instructions; used inside the fast-division domain only, where
+ * every argument is 0 or in [2^-41, 2^58]. */
+__device__ __forceinline__ float ns_sqrt_fast(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+    const float rm = __fmaf_rn(-sm, s, x), rp = __fmaf_rn(-sp, s, x);
+    float r = (0.0f >= rm) ? sm : s;
+    r = (0.0f < rp) ? sp : r;
+    return r;
+}
+
 /* ---- IEEE division without the range scaffolding ------------------------------------------------------
  * The compiler expands a / b into  v_div_scale x2, v_rcp, fma, fma | mul, fma, fma, fma, v_div_fmas |
  * v_div_fixup  (11 vector instructions; a third of the BACK waves' instruction count was division).  For
@@ -212,7 +235,7 @@ __device__ __forceinline__ void noise_track1(float P, float &noise, int nb, floa
         const float upd = (float)(0.9 + 0.1 * (double)r1 * (1.0 + inv));
         n2 *= upd;
     }
-    n2 = sqrtf(n2);
+    n2 = FAST ? SEA_SQRT(n2) : sqrtf(n2);
     noise = (n2 < eps) ? eps : n2;
 }
 
@@ -300,8 +323,8 @@ __device__ __forceinline__ void filter_bins_fast(float PLo, float PHi, float nSi
         noise_track1<true>(PLo, noiseLo, nb, eps);
         noise_track1<true>(PHi, noiseHi, nb, eps);
     }
-    const ns_v2f nSig = {sqrtf(nSigLo), sqrtf(nSigHi)};
-    const ns_v2f P = {sqrtf(PLo), sqrtf(PHi)};
+    const ns_v2f nSig = {SEA_SQRT(nSigLo), SEA_SQRT(nSigHi)};
+    const ns_v2f P = {SEA_SQRT(PLo), SEA_SQRT(PHi)};
     if (ST == 0) { /* VAD-gated noise tracking in magnitude, :531-546 */
         const float lambda = (nb < 100) ? 1 - 1 / (float)nb : (float)0.99;
         if (flagVAD == 0) {
@@ -323,8 +346,8 @@ __device__ __forceinline__ float filter_bin(float P, float nSig, float &noise, f
                                             int flagVAD, float eps)
 {
     if (ST == 1) noise_track1<FAST>(P, noise, nb, eps);
-    nSig = sqrtf(nSig); /* :522-526, (float)sqrt((double)x) == correctly rounded sqrtf */
-    P = sqrtf(P);
+    nSig = FAST ? SEA_SQRT(nSig) : sqrtf(nSig); /* :522-526, (float)sqrt((double)x) == correctly rounded sqrtf */
+    P = FAST ? SEA_SQRT(P) : sqrtf(P);
     if (ST == 0) { /* VAD-gated noise tracking in magnitude, :531-546 */
         const float lambda = (nb < 100) ? 1 - 1 / (float)nb : (float)0.99;
         if (flagVAD == 0) {

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void selftest_log_kernel(const float *x, doubl
  * pseudo-random and edge-mantissa operands spanning the whole domain ns_back() admits: denominators
  * 2^-30 .. 2^59, numerators 0 or 2^-76 .. 2^49 with an exponent difference within [-106, 80]; the double
  * reciprocal on d = 1 + 0.1 r2, r2 in {0} u [2^-100, 2^80].
- * out[0] = float pairs tested, out[1] = float mismatches, out[2] = double mismatches */
+ * out[0] = float pairs tested, out[1] = float mismatches, out[2] = double mismatches,
+ * out[3] = mismatches of ns_sqrt_fast against sqrtf over every float of its range */
 __device__ __forceinline__ unsigned st_hash(unsigned x)
 {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -199,8 +200,17 @@ __global__ __launch_bounds__(256) void selftest_nsdiv_kernel(unsigned long long 
         const double d = 1.0 + 0.1 * (double)r2;
         bad64 += (__double_as_longlong(1.0 / d) != __double_as_longlong(ns_inv64(d))) ? 1 : 0;
     }
+    /* ns_sqrt_fast against sqrtf on EVERY float of its range, 2^-96 .. 2^126, and on 0 */
+    unsigned long long badsq = 0;
+    const unsigned lo = 0x0F800000u, hi = 0x7E800000u;
+    for (unsigned long long v = (unsigned long long)lo + tid; v <= hi; v += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((unsigned)v);
+        badsq += (__float_as_uint(sqrtf(x)) != __float_as_uint(ns_sqrt_fast(x))) ? 1 : 0;
+    }
+    if (tid == 0) badsq += (__float_as_uint(ns_sqrt_fast(0.0f)) != 0u) ? 1 : 0;
     if (bad32) atomicAdd(out + 1, bad32);
     if (bad64) atomicAdd(out + 2, bad64);
+    if (badsq) atomicAdd(out + 3, badsq);
     if (tid == 0) out[0] = (unsigned long long)gridDim.x * blockDim.x * (unsigned long long)iters;
 }
 

@@ -443,10 +443,11 @@ def test_selftest_nsdiv_guarded_division():
     import ctypes
     import speech_enhancement_amd as sea
     _torch()
-    out = (ctypes.c_ulonglong * 3)(0, 99, 99)
+    out = (ctypes.c_ulonglong * 4)(0, 99, 99, 99)
     assert sea.load().sea_selftest_nsdiv(out) == 0
     assert out[0] == 4096 * 256 * 1024
     assert out[1] == 0 and out[2] == 0, f"{out[1]} float / {out[2]} double quotients differ of {out[0]}"
+    assert out[3] == 0, f"{out[3]} square roots differ (every float in [2^-96, 2^126] and 0 is compared)"
 
 
 def test_selftest_div_by_middle_ear_gain():
