@@ -2,23 +2,44 @@
 """bench.py -- headline measurement of the NoiseSup hot path on MI355X.
 
 One "step" = one pass of the hot path over one batch: etsi_denoise semantics (two-stage Wiener
-NoiseSup incl. both 256-point rffts, int16 in -> int16 out) for every utterance of BASELINE.json's
-configs[1] workload, the 1024-utterance synthetic 16 kHz corpus of SURVEY.md 8(d), resident in HBM
-when the timed region starts.  Unit of throughput: NoiseSup frames (80 samples) per second.
+NoiseSup incl. both 256-point rffts, int16 in -> int16 out) for every utterance of the rank's shard,
+resident in HBM when the timed region starts.  Unit of throughput: NoiseSup frames (80 samples) per
+second.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Utterances are independent, so ranks shard the corpus with NO data-path collective (weak scaling:
-every rank owns its own 1024-utterance shard); torch.distributed is used only for the barrier and
-the max-over-ranks of the timed region.  Rank 0 prints ONE JSON line.
+Workloads
+  default               BASELINE configs[1]: every rank owns its own 1024-utterance shard of the
+                        SURVEY 8(d) corpus (weak scaling)
+  --corpus-utts M       BASELINE configs[4]: the M-utterance corpus (100000) cut into --shards S
+                        (default 8) shards balanced by samples (longest-processing-time greedy,
+                        shard.py::lpt_shards); rank r runs shard r, so `--gpus 8 --corpus-utts 100000`
+                        is the whole corpus at 12 500 utterances per GPU and `--gpus 1 --corpus-utts
+                        100000` is one such shard on one GPU.
+
+Multi-GPU: utterances are independent, so ranks shard the corpus with NO data-path collective (the
+reference's own parallel harness is a shared-counter thread pool over files,
+function/20141106_speech_enhancement/aurora_speech_enhancement/aurora_speech_enhancement.cpp:111-121,
+311-327).  torch.distributed (gloo, host side) carries only the barrier and the final (sum of frames,
+max of seconds).  When launched WITHOUT a launcher (`WORLD_SIZE` unset) and --gpus N > 1, this
+process starts the N ranks itself, as child processes, BEFORE anything touches the GPU (torch is not
+even imported in the parent), relays rank 0's JSON line and exits with the worst child status.
+
+Rank 0 prints ONE JSON line.  Besides the headline it carries `roofline`, `cpu_baseline` (N = 1) and
+`also`: the other hot-path kernels (resynth soft / IBM = configs[2] / [3], CompCeps, rfft256), a few
+steps each, timed in the same run.
 """
 import argparse
 import contextlib
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,50 +48,142 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 NS_BYTES_PER_FRAME = 320          # 160 B int16 read + 160 B int16 written
+RS_BYTES_PER_HOP = 896            # 320 B in + 320 B out + 256 B mask row
+CC_BYTES_PER_FRAME = 320 + 56     # 80 new floats read + 14 floats written
+FFT_BYTES_PER_FRAME = 2048        # 256 floats in + 256 floats out
 HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 UTTS_PER_GPU = 1024
+CSRC = os.path.join(ROOT, "speech_enhancement_amd", "csrc")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--utts", type=int, default=UTTS_PER_GPU, help="utterances per GPU (default: configs[1])")
+    ap.add_argument("--corpus-utts", type=int, default=0,
+                    help="configs[4]: size of the whole corpus (100000); rank r runs LPT shard r of --shards")
+    ap.add_argument("--shards", type=int, default=8, help="number of LPT shards the --corpus-utts corpus is cut into")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the resynth / CompCeps / rfft256 lines")
+    ap.add_argument("--also-steps", type=int, default=5)
     ap.add_argument("--cpu-utts", type=int, default=1024, help="utterances in the bounded CPU sample (1024 = ~10 core-seconds)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (the 1-GPU box share is 16)")
-    return ap.parse_args()
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="no GPU work: launcher, gloo rendezvous, shard assignment and the job reduction only (CPU tests)")
+    return ap.parse_args(argv)
 
 
-def build_shard(n_utt, first, device):
-    """The SURVEY 8(d) corpus, utterances first..first+n_utt-1, packed into HBM.  The harmonic part
-    is evaluated with torch on the device (float64), the LCG noise on the host; formula identical to
+# ------------------------------------------------------------------------------------------------
+# rank launcher (parent process: no torch, no HIP)
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """Start n rank processes of this script (env: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR/PORT), wait
+    for all, return the worst exit status.  Rank 0 inherits stdout (its one JSON line is the result)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SEA_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = max(rc, abs(p.returncode))
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic corpus in HBM
+# ------------------------------------------------------------------------------------------------
+_LCG_CACHE = {}
+
+
+def _lcg_tables(n, device):
+    """a^k and c * sum_{j<k} a^j (mod 2^32) for k = 1..n as int64 tensors: state k of the LCG seeded s
+    is (apow[k] * s + cgeo[k]) mod 2^32 (speech_enhancement_amd/corpus.py::lcg_stream)."""
+    import torch
+    key = str(device)
+    if key not in _LCG_CACHE or len(_LCG_CACHE[key][0]) < n:
+        from speech_enhancement_amd import corpus
+        one = corpus.lcg_stream(1, n).astype(np.int64)   # apow + cgeo
+        zero = corpus.lcg_stream(0, n).astype(np.int64)  # cgeo
+        apow = (one - zero) & 0xFFFFFFFF
+        _LCG_CACHE[key] = (torch.from_numpy(apow).to(device), torch.from_numpy(zero).to(device))
+    return _LCG_CACHE[key]
+
+
+def build_shard_ids(ids, device, chunk=128):
+    """The SURVEY 8(d) corpus utterances `ids`, packed into HBM.  Evaluated on the device in chunks of
+    `chunk` utterances (float64 harmonics, int64 LCG); formula identical, element by element, to
     speech_enhancement_amd.corpus.synth_utterance."""
     import torch
     import speech_enhancement_amd as sea
     from speech_enhancement_amd import corpus
-    lengths = np.array([corpus.utterance_length(u) for u in range(first, first + n_utt)], dtype=np.int64)
+    ids = [int(u) for u in ids]
+    lengths = np.array([corpus.utterance_length(u) for u in ids], dtype=np.int64)
     offsets, total, order = sea.PackedBatch.layout(lengths)
     data = torch.zeros(max(total, 8), dtype=torch.int16, device=device)
-    for k, u in enumerate(range(first, first + n_utt)):
-        L = int(lengths[k])
-        i = torch.arange(L, dtype=torch.float64, device=device)
-        f0 = 110 + (u % 97)
-        speech = torch.zeros(L, dtype=torch.float64, device=device)
+    for c0 in range(0, len(ids), chunk):
+        cid = ids[c0:c0 + chunk]
+        Lc = int(lengths[c0:c0 + chunk].max())
+        apow, cgeo = _lcg_tables(96000, device)
+        i = torch.arange(Lc, dtype=torch.float64, device=device)
+        speech = torch.zeros((len(cid), Lc), dtype=torch.float64, device=device)
         for h in range(1, 9):
-            speech += torch.sin(2 * np.pi * h * f0 * i / 16000.0) / h
-        speech *= 3000.0 * ((torch.arange(L, device=device) % 6400) < 3200)
-        s = corpus.lcg_stream(12345 + u, L)
-        noise = ((s >> np.uint32(16)) % np.uint32(1401)).astype(np.int64) - 700
-        x = torch.trunc(speech + torch.from_numpy(noise).to(device)).to(torch.int16)
-        if u % 5 == 0:
-            x[:400] = 0
-        data[int(offsets[k]):int(offsets[k]) + L] = x
+            w = torch.tensor([2 * np.pi * h * (110 + (u % 97)) for u in cid], dtype=torch.float64, device=device)
+            speech += torch.sin(w[:, None] * i[None, :] / 16000.0) / h
+        speech *= (3000.0 * ((torch.arange(Lc, device=device) % 6400) < 3200))[None, :]
+        seeds = torch.tensor([(12345 + u) & 0xFFFFFFFF for u in cid], dtype=torch.int64, device=device)
+        s = (apow[None, :Lc] * seeds[:, None] + cgeo[None, :Lc]) & 0xFFFFFFFF
+        noise = ((s >> 16) % 1401) - 700
+        x = torch.trunc(speech + noise.to(torch.float64)).to(torch.int16)
+        for k, u in enumerate(cid):
+            if u % 5 == 0:
+                x[k, :400] = 0
+            L, o = int(lengths[c0 + k]), int(offsets[c0 + k])
+            data[o:o + L] = x[k, :L]
+        del speech, s, noise, x
     return sea.PackedBatch(data, torch.from_numpy(offsets).to(device), torch.from_numpy(lengths).to(device),
                            torch.from_numpy(order).to(device), offsets, lengths)
 
 
+def build_shard(n_utt, first, device):
+    """Utterances first .. first+n_utt-1 (the configs[1] shard of a rank)."""
+    return build_shard_ids(range(first, first + n_utt), device)
+
+
+def corpus_shard_ids(corpus_utts, shards, rank):
+    """configs[4]: utterance ids of LPT shard `rank` of the corpus_utts-utterance corpus."""
+    from speech_enhancement_amd import corpus
+    from speech_enhancement_amd.shard import lpt_shards
+    lengths = [corpus.utterance_length(u) for u in range(corpus_utts)]
+    return lpt_shards(lengths, shards)[rank % shards]
+
+
+def build_masks(batch, ids, device):
+    """Ratio masks of SURVEY 8(d) for the utterances of `batch` (LCG seeded 777 + u), packed row-wise."""
+    import torch
+    import speech_enhancement_amd as sea
+    rows = (np.asarray(batch.host_lengths) - 320) // 160 + 1
+    offs = np.concatenate(([0], np.cumsum(rows)[:-1])).astype(np.int64)
+    total = int(rows.sum())
+    data = torch.empty((total, 64), dtype=torch.float32, device=device)
+    apow, cgeo = _lcg_tables(96000, device)
+    for k, u in enumerate(ids):
+        n = int(rows[k]) * 64
+        s = (apow[:n] * ((777 + int(u)) & 0xFFFFFFFF) + cgeo[:n]) & 0xFFFFFFFF
+        data[int(offs[k]):int(offs[k]) + int(rows[k])] = (((s >> 16) % 1000).to(torch.float32) / 1000.0).view(-1, 64)
+    return sea.MaskBatch(data, torch.from_numpy(offs).to(device), offs, rows)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle as the thing timed -- allowed here and only here)
+# ------------------------------------------------------------------------------------------------
 @contextlib.contextmanager
 def quiet_stderr():
     """The reference prints 'NO SPEECH DETECTED !' on every call (AdvFrontEnd.c:202-203)."""
@@ -86,56 +199,245 @@ def quiet_stderr():
         os.close(saved)
 
 
-def cpu_baseline(batch, n_sample, threads):
-    """The reference C itself (oracle/_ref, when it was built) or the oracle port, one utterance
-    per thread over all host cores, on the first n_sample utterances of this rank's shard."""
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """gloo prints its rendezvous banner on fd 1; stdout must carry the one JSON line only."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+def init_gloo(rank, world):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    with stdout_to_stderr():
+        dist.init_process_group("gloo", rank=rank, world_size=world)  # host side: barrier + two scalars
+        dist.barrier()
+
+
+def _time_cpu(fn, utts, cores, passes):
     from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as O
-    kind = "reference" if O.have_reference() else "port"
-    lib = O.Reference() if kind == "reference" else O.Oracle()
-    host = batch.data.cpu().numpy()
-    n_sample = min(n_sample, batch.n_utt)
-    utts = [np.ascontiguousarray(host[o:o + l]) for o, l in
-            zip(batch.host_offsets[:n_sample], batch.host_lengths[:n_sample])]
-    frames = int(sum(len(u) // 80 for u in utts))
-    cores = max(1, min(threads, len(os.sched_getaffinity(0))))
-    lib.etsi_denoise(utts[0][:800])  # one-time table init outside the timed region
     outs = [None] * len(utts)
 
     def work(i):
-        outs[i] = lib.etsi_denoise(utts[i])
+        outs[i] = fn(utts[i])
 
-    passes = 3  # ~20 core-seconds of CPU work in total
+    fn(utts[0][:800])  # one-time table init outside the timed region
     with quiet_stderr():
         with ThreadPoolExecutor(max_workers=cores) as ex:
             t0 = time.perf_counter()
             for _ in range(passes):
                 list(ex.map(work, range(len(utts))))
             dt = time.perf_counter() - t0
-    return dict(value=passes * frames / dt, unit="frames/s", cores=cores, kind=kind,
-                sample=f"{passes} passes over the first {len(utts)} utterances of the shard "
-                       f"({passes * frames} frames, {dt:.2f} s wall on {cores} threads)"), outs
+    return dt, outs
 
 
-def main():
-    args = parse_args()
+def cpu_baseline(batch, n_sample, threads):
+    """kind "port": the oracle's C restatement, one utterance per thread over the host cores, on the
+    first n_sample utterances of the shard.  Two builds, as BASELINE.md section 3 promised: the parity
+    build (-O2, no FMA contraction: oracle/libsea_oracle.so) and a speed build compiled HERE for this
+    host (-O3 -march=native); `value` is the faster.  Where oracle/_ref (the reference C compiled from
+    its own sources) shipped with the tree it is timed too and reported beside as `reference_value`."""
+    from oracle import oracle as O
+    host = batch.data.cpu().numpy()
+    n_sample = min(n_sample, batch.n_utt)
+    utts = [np.ascontiguousarray(host[o:o + l]) for o, l in
+            zip(batch.host_offsets[:n_sample], batch.host_lengths[:n_sample])]
+    frames = int(sum(len(u) // 80 for u in utts))
+    cores = max(1, min(threads, len(os.sched_getaffinity(0))))
+    passes = 2
+    parity = O.Oracle()
+    dt_par, outs = _time_cpu(parity.etsi_denoise, utts, cores, passes)
+    res = dict(unit="frames/s", cores=cores, kind="port", parity_build_value=passes * frames / dt_par,
+               parity_build="gcc -O2 -ffp-contract=off (oracle/libsea_oracle.so)")
+    best = res["parity_build_value"]
+    try:  # the speed build must be made on the box it runs on (-march=native)
+        tmp = tempfile.mkdtemp(prefix="sea_cpu_")
+        so = os.path.join(tmp, "libsea_oracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-o", so,
+                               os.path.join(ROOT, "oracle", "ns_oracle.c"), os.path.join(ROOT, "oracle", "resynth_oracle.c"),
+                               "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        speed = O.Oracle(path=so)
+        dt_spd, _ = _time_cpu(speed.etsi_denoise, utts, cores, passes)
+        res["speed_build_value"] = passes * frames / dt_spd
+        res["speed_build"] = "gcc -O3 -march=native (FMA allowed: not bit-exact, timing only)"
+        best = max(best, res["speed_build_value"])
+    except Exception as e:  # no compiler on the box: say so, keep the parity build
+        res["speed_build"] = f"unavailable ({type(e).__name__})"
+    if O.have_reference():
+        dt_ref, _ = _time_cpu(O.Reference().etsi_denoise, utts, cores, passes)
+        res["reference_value"] = passes * frames / dt_ref
+        res["reference_build"] = "the reference's etsi/cpp/*.c, gcc -O2 -ffp-contract=off (oracle/_ref)"
+    res["value"] = best
+    res["sample"] = (f"{passes} passes over the first {len(utts)} utterances of the shard per build "
+                     f"({passes * frames} frames each) on {cores} threads; value = the faster of the port's two builds")
+    return res, outs
+
+
+# ------------------------------------------------------------------------------------------------
+def source_stamp():
+    """sha256 over the kernel sources: profiles/pmc_traffic.json is stamped with it so that a counter
+    figure measured on an older kernel is not reported for a newer one."""
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(CSRC)):
+        if fn.endswith((".hip", ".h", ".c")) or fn == "Makefile":
+            with open(os.path.join(CSRC, fn), "rb") as f:
+                h.update(fn.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(key):
+    """(bytes per launch, note) from profiles/pmc_traffic.json, None when absent or stale."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, "profiles/pmc_traffic.json absent"
+    with open(path) as f:
+        j = json.load(f)
+    if j.get("source_stamp") != source_stamp():
+        return None, (f"profiles/pmc_traffic.json was measured at kernel sources {j.get('source_stamp')}, "
+                      f"this tree is {source_stamp()}: stale, not reported (tools/profile_round.sh refreshes it)")
+    return j.get(key), f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at kernel sources {j['source_stamp']}"
+
+
+def timed_steps(fn, steps, warmup):
+    """HIP-event time per call of fn() on torch's current stream (the stream every launch of
+    speech_enhancement_amd goes to); returns (mean seconds, wall seconds per step)."""
+    import torch
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps
+    return float(np.mean([a.elapsed_time(b) for a, b in ev])) / 1e3, wall
+
+
+def also_lines(batch, ids, device, steps):
+    """configs[2], configs[3], CompCeps and rfft256 on the same shard, same run."""
+    import torch
+    import speech_enhancement_amd as sea
+    out = []
+    audio_s = float(np.sum(batch.host_lengths)) / 16000.0
+
+    def line(name, workload, units, unit, alg_bytes, ker_s, wall_s, kernel, traffic_key, extra=None):
+        traffic, note = pmc_traffic(traffic_key)
+        d = {"name": name, "workload": workload, "value": units / wall_s, "unit": unit, "ms_per_step": wall_s * 1e3,
+             "steps": steps, "rtf": wall_s / audio_s,
+             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": alg_bytes / ker_s / 1e9, "peak": HBM_PEAK_GBPS,
+                          "unit": "GB/s", "frac": alg_bytes / ker_s / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                          "traffic_over_algorithmic": (traffic / alg_bytes) if traffic else None,
+                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": ker_s * 1e3}}
+        if extra:
+            d.update(extra)
+        out.append(d)
+
+    # resynth, ratio mask and ideal binary mask (configs[2], configs[3])
+    masks = build_masks(batch, ids, device)
+    hops = int(np.sum((np.asarray(batch.host_lengths) - 320) // 160 + 1))
+    scratch = torch.empty(sea.resynth_scratch_elems(batch), dtype=torch.float32, device=device)
+    rs_out = torch.zeros_like(batch.data)
+    for name, binary, cfg in (("resynth_64sub_ori", False, 2), ("resynth_64sub_IBM", True, 3)):
+        ker, wall = timed_steps(lambda: sea.resynth_batch(batch, masks, binary=binary, out=rs_out, scratch=scratch), steps, 1)
+        line(name, f"BASELINE configs[{cfg}]: {batch.n_utt} utterances, 64-band gammatone analysis/synthesis, "
+                   f"{'ideal binary' if binary else 'ratio'} mask, {hops} hop-frames of 160 samples",
+             hops, "hop-frames/s", hops * RS_BYTES_PER_HOP, ker, wall, "sea::resynth_fused_kernel",
+             "resynth_bytes_per_launch",
+             {"intermediate_bytes_per_launch": int(batch.total) * 64 * 4 * 2})
+    del scratch, rs_out, masks
+
+    # CompCeps from the float NoiseSup stream
+    _, f32, first = sea.ns_denoise_batch(batch, want_f32=True)
+    torch.cuda.synchronize()
+    res = {}
+
+    def run_cc():
+        res["c"] = sea.compceps_batch(batch, f32, first)
+    ker, wall = timed_steps(run_cc, steps, 1)
+    n = int(res["c"][2].sum().item())
+    line("CompCeps", f"{batch.n_utt} utterances, {n} cepstral frames (window 200, hop 80) of 14 coefficients from the float NoiseSup stream",
+         n, "frames/s", n * CC_BYTES_PER_FRAME, ker, wall, "sea::compceps_kernel", "compceps_bytes_per_launch")
+    del f32, res
+
+    # rfft256 on a streaming batch
+    nfr = 1 << 18
+    x = torch.randn(nfr, 256, device=device)
+    y = torch.empty_like(x)
+    lib = sea.load()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run_fft():
+        assert lib.sea_rfft256_batch(x.data_ptr(), y.data_ptr(), nfr, st) == 0
+    ker, wall = timed_steps(run_fft, steps, 1)
+    line("rfft256", f"{nfr} frames of 256 floats (etsi/cpp/rfft.c), out of place", nfr, "frames/s",
+         nfr * FFT_BYTES_PER_FRAME, ker, wall, "sea::rfft256_kernel", "rfft256_bytes_per_launch")
+    return out
+
+
+def rehearse_cpu(args, world, rank):
+    """The N > 1 control path without a GPU: every rank takes its shard of the corpus (ids only), the
+    ranks meet at the gloo barrier and reduce (sum of frames, max of seconds) as the real run does."""
+    import torch.distributed as dist
+    from speech_enhancement_amd import corpus
+    from speech_enhancement_amd.shard import reduce_job
+    if world > 1:
+        init_gloo(rank, world)
+    ids = (corpus_shard_ids(args.corpus_utts, args.shards, rank) if args.corpus_utts > 0
+           else list(range(rank * args.utts, (rank + 1) * args.utts)))
+    frames = int(sum(corpus.utterance_length(int(u)) // 80 for u in ids))
+    if world > 1:
+        dist.barrier()
+    total, tmax = reduce_job(frames * args.steps, 1.0 + rank, dist if world > 1 else None)
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": args.steps, "total_frames": total,
+                          "seconds_max": tmax, "utterances_rank0": len(ids), "first_ids_rank0": [int(u) for u in ids[:4]]}),
+              flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def run_rank(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse_cpu:
+        return rehearse_cpu(args, world, rank)
     import torch
     import torch.distributed as dist
     import speech_enhancement_amd as sea
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % n_dev  # ranks > devices only when rehearsing N ranks on a smaller box
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        init_gloo(rank, world)
 
     sea.load().sea_init(-1)
-    batch = build_shard(args.utts, rank * args.utts, device)
+    if args.corpus_utts > 0:
+        ids = corpus_shard_ids(args.corpus_utts, args.shards, rank)
+        workload = (f"BASELINE configs[4]: {args.corpus_utts}-utterance synthetic corpus in {args.shards} LPT shards "
+                    f"(balanced by samples), one shard per GPU; this run: {world} of {args.shards} shard(s), "
+                    f"{len(ids)} utterances on rank 0")
+    else:
+        ids = list(range(rank * args.utts, (rank + 1) * args.utts))
+        workload = (f"BASELINE configs[1]: {args.utts}-utterance batch per GPU, 256-pt rfft + two-stage Wiener "
+                    "NoiseSup (etsi_denoise semantics), SURVEY 8(d) synthetic 16 kHz corpus, 2-6 s utterances")
+    batch = build_shard_ids(ids, device)
     out = torch.zeros_like(batch.data)
     frames_per_step = batch.n_frames
     audio_s_per_step = frames_per_step * 80 / 16000.0
@@ -144,6 +446,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
 
     for _ in range(args.warmup):
         sea.ns_denoise_batch(batch, out=out)
@@ -155,24 +459,27 @@ def main():
         events[k][0].record()
         sea.ns_denoise_batch(batch, out=out)
         events[k][1].record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0   # this rank's timed region; the job's is the max over ranks
     barrier()
-    dt = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in events]
 
     # whole-job aggregate: frames summed over ranks, time = max over ranks (no data-path collective)
     from speech_enhancement_amd.shard import reduce_job
-    total_frames, dt_max = reduce_job(frames_per_step * args.steps, dt, dist if world > 1 else None, device)
+    total_frames, dt_max = reduce_job(frames_per_step * args.steps, dt, dist if world > 1 else None)
     value = total_frames / dt_max
 
-    result = None
+    result, rc = None, 0
     if rank == 0:
         avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
         achieved = frames_per_step * NS_BYTES_PER_FRAME / avg_kernel_s / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path) and args.utts == UTTS_PER_GPU:
-            with open(pmc_path) as f:
-                traffic = json.load(f).get("ns_denoise_kernel_bytes_per_launch")
+        traffic, traffic_note = (pmc_traffic("ns_denoise_kernel_bytes_per_launch")
+                                 if (args.corpus_utts == 0 and args.utts == UTTS_PER_GPU) else (None, "measured for configs[1] only"))
+        forced = os.environ.get("SEA_NS_KERNEL")
+        per_cu = batch.n_utt / 256.0
+        kernel = {"single": "sea::ns_denoise_kernel", "pipe": "sea::ns_denoise_pipe_kernel", "pipe6": "sea::ns_denoise_pipe6_kernel",
+                  "big": "sea::ns_denoise_pipe_big_kernel"}.get(forced) or (
+            "sea::ns_denoise_pipe6_kernel" if per_cu <= 2 else ("sea::ns_denoise_pipe_kernel" if per_cu <= 4 else "sea::ns_denoise_pipe_big_kernel"))
         result = {
             "metric": "NoiseSup frames/sec (16 kHz, hop 80, 256-pt rfft, two-stage Wiener), batched",
             "value": value,
@@ -186,24 +493,25 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "rtf": dt_max / (audio_s_per_step * args.steps * world),
+            "rtf": dt_max / (total_frames * 80 / 16000.0),
             "config": {
-                "workload": "BASELINE configs[1]: 1024-utterance batch per GPU, 256-pt rfft + two-stage Wiener "
-                            "NoiseSup (etsi_denoise semantics), SURVEY 8(d) synthetic 16 kHz corpus, 2-6 s utterances",
-                "utterances_per_gpu": args.utts,
+                "workload": workload,
+                "utterances_per_gpu": batch.n_utt,
                 "frames_per_step_per_gpu": frames_per_step,
                 "audio_seconds_per_step_per_gpu": audio_s_per_step,
-                "sharding": f"{world} independent shard(s), no collective on the data path",
+                "sharding": f"{world} independent shard(s), no collective on the data path (gloo barrier + 2 scalars only)",
+                "devices_visible": n_dev,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "sea::ns_denoise_kernel" if os.environ.get("SEA_NS_KERNEL") == "single"
-                          else "sea::ns_denoise_pipe_kernel",
+                "limiter": "vector-instruction issue and dependent latency, not HBM (DESIGN.md 5.1); frac is the HBM fraction BASELINE asks for",
+                "kernel": kernel,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
+                "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": frames_per_step * NS_BYTES_PER_FRAME,
                 "avg_launch_ms": avg_kernel_s * 1e3,
             },
@@ -211,17 +519,31 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N=1 only
             base, outs = cpu_baseline(batch, args.cpu_utts, args.cpu_threads)
             result["cpu_baseline"] = base
-            # parity spot check on the sample (the oracle as checker, never as the measured path)
+            # parity on the sample, exact (the oracle as checker, never as the measured path)
             got = batch.split(out, full_frames_only=True)
-            bad = sum(int(np.abs(g.astype(np.int32) - o[:len(g)].astype(np.int32)).max() > 2)
-                      for g, o in zip(got[:len(outs)], outs) if len(g))
-            result["parity_check"] = f"{len(outs) - bad}/{len(outs)} sampled utterances within 2 LSB of the CPU {base['kind']}"
+            bad = sum(int(not np.array_equal(g, o[:len(g)])) for g, o in zip(got[:len(outs)], outs))
+            result["parity_check"] = f"{len(outs) - bad}/{len(outs)} sampled utterances bit-identical to the CPU oracle"
             result["gpu_over_cpu"] = value / base["value"]
-    barrier()
+            if bad:
+                rc = 3
+        if not args.no_also and world == 1:
+            del out
+            result["also"] = also_lines(batch, ids, device, args.also_steps)
+    if world > 1:
+        dist.barrier()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    return rc
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the ranks ourselves, from a process that never touches the GPU
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

@@ -173,8 +173,8 @@ int sea_ns_streams_push_fd(const float *d_in, float *d_out, int *d_produced, uns
                            int *d_frame_counter, float *d_state, int n_streams, int nframes, int reset, void *stream);
 
 /* ----------------------------------------------------------------------------------------------
- * device self-tests of the two places where a kernel takes a cheaper route than the reference's
- * literal arithmetic (both proven / guarded, see csrc/sea_device.h and csrc/ns_kernel.hip)
+ * device self-tests of the places where a kernel takes a cheaper route than the reference's
+ * literal arithmetic (each proven or guarded, see csrc/sea_device.h, csrc/ns_core.h and DESIGN.md section 3)
  * -------------------------------------------------------------------------------------------- */
 /* all 2^32 floats s: (float)((double)s * (1/sqrt2)) vs (float)((double)s / sqrt2); count of differences */
 int sea_selftest_pi4(unsigned long long *n_mismatch);
@@ -194,6 +194,18 @@ int sea_selftest_nsdiv(unsigned long long *out4);
 int sea_selftest_dc(const float *dif, const float *y0, float *out, int *fellback, int ncases);
 /* the kernels' own double-precision natural log (positive normal arguments) on n floats (host pointers) */
 int sea_selftest_log(const float *x, double *ln_out, int n);
+/* the guard around that log (csrc/ns_core.h, ns_near_float_boundary): both call sites round a double expression
+ * of the log to float (NoiseSup.c:391, :607); when the expression lands within a few ulps of a float rounding
+ * boundary the log is redone in double-double arithmetic (site 2: through the fdlibm log10 formula glibc uses).
+ *   sea_selftest_log_dd     the double-double log itself on n doubles (host pointers): hi + lo
+ *   sea_selftest_log_sites  both complete sites on n floats: site1 = VAD frame log-energy of frameSum = x
+ *                           (x >= 64), site2 = averSNR of x (x > 1e-5); NaN outside a site's range
+ *   sea_selftest_log_guard  sweeps EVERY float argument of site 1 ([64, 2^37]) or 2 (every float > 1e-5):
+ *                           stats4 = {arguments, guard hits, hits where the slow path changed the float, hits
+ *                           recorded}; hits3 receives up to cap triples (argument, fast float, returned float) */
+int sea_selftest_log_dd(const double *x, double *hi, double *lo, int n);
+int sea_selftest_log_sites(const float *x, float *site1, float *site2, int n);
+int sea_selftest_log_guard(int site, unsigned long long *stats4, float *hits3, int cap);
 
 #ifdef __cplusplus
 }

@@ -128,10 +128,11 @@ class _Lib:
 
 
 class Oracle(_Lib):
-    def __init__(self):
-        if not os.path.exists(ORACLE_SO):
+    def __init__(self, path=None):
+        """path: another build of the SAME restatement (bench.py's -O3 -march=native timing build)."""
+        if path is None and not os.path.exists(ORACLE_SO):
             build(ref=False)
-        super().__init__(ORACLE_SO, "ora_")
+        super().__init__(path or ORACLE_SO, "ora_")
         self.lib.ora_resynth64.restype = ctypes.c_int
 
     def resynth64(self, x, mask, binary=False, frames_l_over_160=False):

@@ -7,7 +7,9 @@ Only what that path needs lives here:
   csrc/       HIP kernels, host table builder, the C ABI (libsea_mi355x.so, built in-tree)
   engine.py   host-side mirror of the reference interface + batched HBM-resident forms
   corpus.py   the deterministic synthetic corpus the measurements run on
-  wavio.py / cli.py   deal.sh-style cfg -> list -> WAV file-in/file-out drivers
+  shard.py    utterance sharding over the GPUs of a node (LPT / blocks) and the two-scalar job reduction
+  host/       plain-C drivers with the reference's command lines (cfg -> list -> WAV in / WAV out) and the
+              mask text format; deal/*.sh build them
 """
 from . import corpus  # noqa: F401
 from ._lib import LIB_PATH, SeaError, load  # noqa: F401

@@ -54,6 +54,9 @@ PROTOTYPES = {
     "sea_selftest_nsdiv": (_i, [_vp]),
     "sea_selftest_dc": (_i, [_vp, _vp, _vp, _vp, _i]),
     "sea_selftest_log": (_i, [_vp, _vp, _i]),
+    "sea_selftest_log_dd": (_i, [_vp, _vp, _vp, _i]),
+    "sea_selftest_log_sites": (_i, [_vp, _vp, _vp, _i]),
+    "sea_selftest_log_guard": (_i, [_i, _vp, _vp, _i]),
 }
 
 _lib = None

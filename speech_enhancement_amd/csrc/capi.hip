@@ -107,53 +107,72 @@ struct HostWs {
     int *h_order = nullptr, *d_order = nullptr;
     size_t cap = 0, cap_utt = 0;
     hipStream_t stream = nullptr;
+    int device = -1; /* the device every buffer and the stream belong to */
     ~HostWs() { release(); }
-    void release()
+    void release_samples()
     {
         if (h_in) (void)hipHostFree(h_in);
         if (h_out) (void)hipHostFree(h_out);
-        if (h_meta) (void)hipHostFree(h_meta);
-        if (h_order) (void)hipHostFree(h_order);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
+        h_in = h_out = d_in = d_out = nullptr;
+        cap = 0;
+    }
+    void release_meta()
+    {
+        if (h_meta) (void)hipHostFree(h_meta);
+        if (h_order) (void)hipHostFree(h_order);
         if (d_meta) (void)hipFree(d_meta);
         if (d_order) (void)hipFree(d_order);
-        h_in = h_out = d_in = d_out = nullptr;
         h_meta = d_meta = nullptr;
         h_order = d_order = nullptr;
-        cap = cap_utt = 0;
+        cap_utt = 0;
     }
+    void release()
+    {
+        release_samples();
+        release_meta();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+        device = -1;
+    }
+    /* A failed allocation leaves the group it belongs to empty (nothing half-allocated is kept). */
     hipError_t ensure(size_t samples, size_t n_utt)
     {
         hipError_t e;
+        int dev = -1;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if (dev != device) { /* the thread moved to another device (hipSetDevice): nothing of the old one is usable */
+            if (device >= 0) {
+                (void)hipSetDevice(device);
+                release();
+                (void)hipSetDevice(dev);
+            }
+            device = dev;
+        }
         if (!stream && (e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return e;
         if (samples > cap) {
             const size_t want = samples + samples / 4 + 4096;
-            if (h_in) (void)hipHostFree(h_in);
-            if (h_out) (void)hipHostFree(h_out);
-            if (d_in) (void)hipFree(d_in);
-            if (d_out) (void)hipFree(d_out);
-            h_in = h_out = d_in = d_out = nullptr;
-            cap = 0;
-            if ((e = hipHostMalloc((void **)&h_in, want * sizeof(short), hipHostMallocDefault)) != hipSuccess) return e;
-            if ((e = hipHostMalloc((void **)&h_out, want * sizeof(short), hipHostMallocDefault)) != hipSuccess) return e;
-            if ((e = hipMalloc((void **)&d_in, want * sizeof(short) + 16)) != hipSuccess) return e;
-            if ((e = hipMalloc((void **)&d_out, want * sizeof(short) + 16)) != hipSuccess) return e;
+            release_samples();
+            if ((e = hipHostMalloc((void **)&h_in, want * sizeof(short), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipHostMalloc((void **)&h_out, want * sizeof(short), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void **)&d_in, want * sizeof(short) + 16)) != hipSuccess ||
+                (e = hipMalloc((void **)&d_out, want * sizeof(short) + 16)) != hipSuccess) {
+                release_samples();
+                return e;
+            }
             cap = want;
         }
         if (n_utt > cap_utt) {
             const size_t want = n_utt + n_utt / 4 + 16;
-            if (h_meta) (void)hipHostFree(h_meta);
-            if (h_order) (void)hipHostFree(h_order);
-            if (d_meta) (void)hipFree(d_meta);
-            if (d_order) (void)hipFree(d_order);
-            h_meta = d_meta = nullptr;
-            h_order = d_order = nullptr;
-            cap_utt = 0;
-            if ((e = hipHostMalloc((void **)&h_meta, 2 * want * sizeof(long long), hipHostMallocDefault)) != hipSuccess) return e;
-            if ((e = hipHostMalloc((void **)&h_order, want * sizeof(int), hipHostMallocDefault)) != hipSuccess) return e;
-            if ((e = hipMalloc((void **)&d_meta, 2 * want * sizeof(long long))) != hipSuccess) return e;
-            if ((e = hipMalloc((void **)&d_order, want * sizeof(int))) != hipSuccess) return e;
+            release_meta();
+            if ((e = hipHostMalloc((void **)&h_meta, 2 * want * sizeof(long long), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipHostMalloc((void **)&h_order, want * sizeof(int), hipHostMallocDefault)) != hipSuccess ||
+                (e = hipMalloc((void **)&d_meta, 2 * want * sizeof(long long))) != hipSuccess ||
+                (e = hipMalloc((void **)&d_order, want * sizeof(int))) != hipSuccess) {
+                release_meta();
+                return e;
+            }
             cap_utt = want;
         }
         return hipSuccess;
@@ -550,47 +569,89 @@ int sea_resynth64(const short *in, long L, const float *mask, int F, int binary,
     return 0;
 }
 
-int sea_resynth_utterances(const short *const *in, const long *lengths, const float *const *masks, int binary,
-                           short *const *out, int n_utt)
+/* One sub-batch [u0, u1) of sea_resynth_utterances: pack, upload, one launch, download. */
+static int resynth_sub_batch(const short *const *in, const long *lengths, const float *const *masks, int binary,
+                             short *const *out, int u0, int u1, float *d_inter)
 {
-    if (n_utt <= 0) return 0;
-    std::vector<long long> offs(n_utt), lens(n_utt), moffs(n_utt);
+    const int n = u1 - u0;
+    std::vector<long long> offs(n), lens(n), moffs(n);
     long long total = 0, rows = 0;
-    for (int u = 0; u < n_utt; ++u) {
-        if (lengths[u] < ((binary & 2) ? 160 : 320))
-            return fail("resynth: utterance %d has %ld samples (too short for one mask frame)", u, lengths[u]);
-        offs[u] = total;
-        lens[u] = lengths[u];
-        moffs[u] = rows;
-        total += align8(lengths[u]);
-        rows += (binary & 2) ? lengths[u] / 160 : (lengths[u] - 320) / 160 + 1;
+    auto nrows = [&](long L) { return (binary & 2) ? L / 160 : (L - 320) / 160 + 1; };
+    for (int k = 0; k < n; ++k) {
+        offs[k] = total;
+        lens[k] = lengths[u0 + k];
+        moffs[k] = rows;
+        total += align8(lens[k]);
+        rows += nrows(lengths[u0 + k]);
     }
     std::vector<short> pack((size_t)total, 0);
     std::vector<float> mpack((size_t)rows * 64);
-    for (int u = 0; u < n_utt; ++u) {
-        memcpy(&pack[(size_t)offs[u]], in[u], (size_t)lens[u] * sizeof(short));
-        memcpy(&mpack[(size_t)moffs[u] * 64], masks[u],
-               (size_t)((binary & 2) ? lens[u] / 160 : (lens[u] - 320) / 160 + 1) * 64 * sizeof(float));
+    for (int k = 0; k < n; ++k) {
+        memcpy(&pack[(size_t)offs[k]], in[u0 + k], (size_t)lens[k] * sizeof(short));
+        memcpy(&mpack[(size_t)moffs[k] * 64], masks[u0 + k], (size_t)nrows(lengths[u0 + k]) * 64 * sizeof(float));
     }
     DevBuf<short> din, dout;
-    DevBuf<float> dmask, dinter;
+    DevBuf<float> dmask;
     DevBuf<long long> dmeta;
     HIP_TRY(din.alloc((size_t)total));
     HIP_TRY(dout.alloc((size_t)total));
     HIP_TRY(dmask.alloc(mpack.size()));
-    HIP_TRY(dinter.alloc((size_t)sea_resynth_scratch_bytes(total, n_utt) / sizeof(float)));
-    HIP_TRY(dmeta.alloc(3 * (size_t)n_utt));
+    HIP_TRY(dmeta.alloc(3 * (size_t)n));
     HIP_TRY(hipMemcpy(din.p, pack.data(), (size_t)total * sizeof(short), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dmask.p, mpack.data(), mpack.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dmeta.p, offs.data(), n_utt * sizeof(long long), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dmeta.p + n_utt, lens.data(), n_utt * sizeof(long long), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dmeta.p + 2 * n_utt, moffs.data(), n_utt * sizeof(long long), hipMemcpyHostToDevice));
-    if (sea_resynth64_batch(din.p, dout.p, dmeta.p, dmeta.p + n_utt, dmask.p, dmeta.p + 2 * n_utt, dinter.p, nullptr,
-                            n_utt, binary, nullptr))
+    HIP_TRY(hipMemcpy(dmeta.p, offs.data(), n * sizeof(long long), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dmeta.p + n, lens.data(), n * sizeof(long long), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dmeta.p + 2 * n, moffs.data(), n * sizeof(long long), hipMemcpyHostToDevice));
+    if (sea_resynth64_batch(din.p, dout.p, dmeta.p, dmeta.p + n, dmask.p, dmeta.p + 2 * n, d_inter, nullptr, n, binary,
+                            nullptr))
         return 1;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(pack.data(), dout.p, (size_t)total * sizeof(short), hipMemcpyDeviceToHost));
-    for (int u = 0; u < n_utt; ++u) memcpy(out[u], &pack[(size_t)offs[u]], (size_t)lens[u] * sizeof(short));
+    for (int k = 0; k < n; ++k) memcpy(out[u0 + k], &pack[(size_t)offs[k]], (size_t)lens[k] * sizeof(short));
+    return 0;
+}
+
+/* The [time][64] float intermediate costs 256 B of HBM per sample (~16 MB per 4-s utterance): the list is cut
+ * into sub-batches whose scratch fits in 60 % of the HBM that is free right now (SEA_RESYNTH_SCRATCH_MB overrides
+ * the budget), and ONE scratch allocation is reused by all of them.  The reference processes one utterance at a
+ * time (resyth_64sub_ori/cpp/main.cpp:84-145); results do not depend on the cut. */
+int sea_resynth_utterances(const short *const *in, const long *lengths, const float *const *masks, int binary,
+                           short *const *out, int n_utt)
+{
+    if (n_utt <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    long long largest = 0;
+    for (int u = 0; u < n_utt; ++u) {
+        if (lengths[u] < ((binary & 2) ? 160 : 320))
+            return fail("resynth: utterance %d has %ld samples (too short for one mask frame)", u, lengths[u]);
+        largest = std::max(largest, sea_resynth_scratch_bytes(align8(lengths[u]), 1));
+    }
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    long long budget = (long long)(free_b / 10 * 6);
+    if (const char *e = getenv("SEA_RESYNTH_SCRATCH_MB")) budget = atoll(e) * (1LL << 20);
+    if (budget < largest) budget = largest; /* one utterance must fit; hipMalloc reports it if it does not */
+    /* cut: greedy runs of consecutive utterances within the budget */
+    std::vector<int> cuts(1, 0);
+    long long run = 0, run_max = 0;
+    int run_n = 0;
+    for (int u = 0; u < n_utt; ++u) {
+        const long long need = sea_resynth_scratch_bytes(run + align8(lengths[u]), run_n + 1);
+        if (run_n > 0 && need > budget) {
+            cuts.push_back(u);
+            run = 0;
+            run_n = 0;
+        }
+        run += align8(lengths[u]);
+        run_n++;
+        run_max = std::max(run_max, sea_resynth_scratch_bytes(run, run_n));
+    }
+    cuts.push_back(n_utt);
+    DevBuf<float> dinter;
+    HIP_TRY(dinter.alloc((size_t)run_max / sizeof(float)));
+    for (size_t k = 0; k + 1 < cuts.size(); ++k)
+        if (resynth_sub_batch(in, lengths, masks, binary, out, cuts[k], cuts[k + 1], dinter.p)) return 1;
     return 0;
 }
 
@@ -681,7 +742,8 @@ int sea_ns_stream_push(sea_ns_stream *s, const float *in80, float *out80)
     DeviceCtx *c;
     if (!s || ctx(&c)) {
         fprintf(stderr, "ERROR:   DoNoiseSup (MI355X): %s\r\n", s ? g_err : "NULL stream");
-        exit(0); /* the reference's DoNoiseSup path ends the process on failure (NoiseSup.c:983-987) */
+        exit(1); /* the reference's DoNoiseSup path ends the process on failure (NoiseSup.c:983-987: exit(0));
+                  * a device fault must not look like success to the caller's shell, so the status is non-zero */
     }
     sea::NsStreamArgs a = {};
     a.in = s->io;
@@ -701,7 +763,7 @@ int sea_ns_stream_push(sea_ns_stream *s, const float *in80, float *out80)
     if (ok && produced) ok = hipMemcpy(out80, s->io + 80, 80 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
     if (!ok) {
         fprintf(stderr, "ERROR:   DoNoiseSup (MI355X): device failure\r\n");
-        exit(0);
+        exit(1);
     }
     s->fresh = 0;
     return produced;
@@ -838,6 +900,62 @@ int sea_selftest_log(const float *x, double *ln_out, int n)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(ln_out, dout.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sea_selftest_log_dd(const double *x, double *hi, double *lo, int n)
+{
+    if (n <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    DevBuf<double> dx, dhi, dlo;
+    HIP_TRY(dx.alloc(n));
+    HIP_TRY(dhi.alloc(n));
+    HIP_TRY(dlo.alloc(n));
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sea::selftest_log_dd_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, dx.p, dhi.p, dlo.p, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(hi, dhi.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(lo, dlo.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sea_selftest_log_sites(const float *x, float *site1, float *site2, int n)
+{
+    if (n <= 0) return 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    DevBuf<float> dx, d1, d2;
+    HIP_TRY(dx.alloc(n));
+    HIP_TRY(d1.alloc(n));
+    HIP_TRY(d2.alloc(n));
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sea::selftest_log_sites_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, dx.p, d1.p, d2.p, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(site1, d1.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(site2, d2.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int sea_selftest_log_guard(int site, unsigned long long *stats4, float *hits3, int cap)
+{
+    if (site != 1 && site != 2) return fail("selftest_log_guard: site must be 1 or 2");
+    if (cap < 0) cap = 0;
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    DevBuf<unsigned long long> ds;
+    DevBuf<float> dh;
+    HIP_TRY(ds.alloc(4));
+    HIP_TRY(dh.alloc((size_t)3 * (cap > 0 ? cap : 1)));
+    HIP_TRY(hipMemset(ds.p, 0, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(dh.p, 0, (size_t)3 * (cap > 0 ? cap : 1) * sizeof(float)));
+    hipLaunchKernelGGL(sea::selftest_log_guard_kernel, dim3(4096), dim3(256), 0, nullptr, site, ds.p, dh.p, cap);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(stats4, ds.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (cap > 0 && hits3) HIP_TRY(hipMemcpy(hits3, dh.p, (size_t)3 * cap * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -152,6 +152,148 @@ __device__ __forceinline__ double ns_ln(double x)
     return __fma_rn(de, ln2_hi, __fma_rn(de, ln2_lo, lnm));
 }
 
+/* ---- the guard of the lean log --------------------------------------------------------------------------
+ * Both call sites round a short double expression of the log to float (NoiseSup.c:391, :607).  ns_ln is within
+ * 0.69 ulp of ln; glibc's log (what the reference calls) within 0.52 ulp, its log10 within 2 ulp.  The float can
+ * only differ when the double expression lands within a few double ulps of a float ROUNDING BOUNDARY (the low 29
+ * bits of its significand = 2^28).  ns_near_float_boundary() tests exactly that, with a window K that covers
+ * both logs' error bounds propagated through the expression (site 1: 1.21 ulp of the log -> <= 4.4 ulp of the
+ * result, K = 8; site 2: 4.5 ulp -> <= 13, K = 16).  Inside the window (probability (2K+1) 2^-29 per call:
+ * 3e-8 / 6e-8) the logarithm is recomputed in double-double arithmetic, accurate to 2^-80, and rounded once --
+ * the correctly rounded value, which is what glibc's log returns in all but ~4 % of such cases; at site 2 it is
+ * put through the very formula glibc's log10 uses (fdlibm e_log10.c:  z = k log10_2lo + ivln10 log(x'),
+ * z + k log10_2hi, verified equal to this image's log10 on 2 M arguments).  What remains is the reference libm's own
+ * last-bit freedom (its log has CPU-specific FMA variants): ~1e-10 per call, against ~4e-9 without the guard.
+ * sea_selftest_log sweeps EVERY float argument either site can see and reports the guard hits. */
+__device__ __forceinline__ bool ns_near_float_boundary(double v, int K)
+{
+    const int low = (int)((unsigned)__double_as_longlong(v) & 0x1FFFFFFFu); /* bits below a float's 24-bit significand */
+    const int d = low - 0x10000000;
+    return (d <= K) && (d >= -K);
+}
+
+struct NsDD {
+    double hi, lo;
+};
+__device__ __forceinline__ NsDD dd_fast_two_sum(double a, double b) /* |a| >= |b| */
+{
+    const double s = a + b;
+    return NsDD{s, b - (s - a)};
+}
+__device__ __forceinline__ NsDD dd_two_sum(double a, double b)
+{
+    const double s = a + b, bb = s - a;
+    return NsDD{s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ NsDD dd_two_prod(double a, double b)
+{
+    const double p = a * b;
+    return NsDD{p, __fma_rn(a, b, -p)};
+}
+__device__ __forceinline__ NsDD dd_add(NsDD a, NsDD b)
+{
+    NsDD s = dd_two_sum(a.hi, b.hi);
+    const NsDD t = dd_two_sum(a.lo, b.lo);
+    s = dd_fast_two_sum(s.hi, s.lo + t.hi);
+    return dd_fast_two_sum(s.hi, s.lo + t.lo);
+}
+__device__ __forceinline__ NsDD dd_mul(NsDD a, NsDD b)
+{
+    NsDD p = dd_two_prod(a.hi, b.hi);
+    p.lo += a.hi * b.lo + a.lo * b.hi;
+    return dd_fast_two_sum(p.hi, p.lo);
+}
+/* natural logarithm of a positive normal double as an unevaluated sum hi + lo, relative error < 2^-80:
+ * x = m 2^e, m in [sqrt(1/2), sqrt 2), f = (m-1)/(m+1) in double-double, ln m = 2 f sum_k f^2k/(2k+1) (k <= 17:
+ * f^2 <= 0.0295; the terms k >= 6 are below 1e-10 and run in plain double), ln x = e ln2 + ln m. */
+__device__ __attribute__((noinline)) NsDD ns_ln_dd(double x)
+{
+    const long long bits = __double_as_longlong(x);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+    if (m > 1.4142135623730951) {
+        m *= 0.5;
+        e += 1;
+    }
+    const double n = m - 1.0;            /* exact (Sterbenz) */
+    const NsDD d = dd_two_sum(m, 1.0);   /* m + 1 may need 54 bits */
+    /* f = n / d: two quotient digits, remainder taken exactly */
+    const double q1 = n / d.hi;
+    const NsDD p1 = dd_two_prod(q1, d.hi);
+    const double r = ((n - p1.hi) - p1.lo) - q1 * d.lo;
+    const double q2 = r / d.hi;
+    const NsDD f = dd_fast_two_sum(q1, q2);
+    const NsDD f2 = dd_mul(f, f);
+    double t = 1.0 / 35.0;               /* sum_{k=6..17} f2^(k-6) / (2k+1), Horner in double (f2^6 < 7e-10) */
+    t = __fma_rn(t, f2.hi, 1.0 / 33.0);
+    t = __fma_rn(t, f2.hi, 1.0 / 31.0);
+    t = __fma_rn(t, f2.hi, 1.0 / 29.0);
+    t = __fma_rn(t, f2.hi, 1.0 / 27.0);
+    t = __fma_rn(t, f2.hi, 1.0 / 25.0);
+    t = __fma_rn(t, f2.hi, 1.0 / 23.0);
+    t = __fma_rn(t, f2.hi, 1.0 / 21.0);
+    t = __fma_rn(t, f2.hi, 1.0 / 19.0);
+    t = __fma_rn(t, f2.hi, 1.0 / 17.0);
+    t = __fma_rn(t, f2.hi, 1.0 / 15.0);
+    t = __fma_rn(t, f2.hi, 1.0 / 13.0);
+    /* S = 1 + f2 (1/3 + f2 (1/5 + f2 (1/7 + f2 (1/9 + f2 (1/11 + f2 t))))) in double-double; constants to 106 bits */
+    NsDD S = dd_mul(f2, NsDD{t, 0.0});
+    S = dd_mul(f2, dd_add(S, NsDD{0.090909090909090912, -2.5232341468753558e-18}));
+    S = dd_mul(f2, dd_add(S, NsDD{0.1111111111111111, 6.1679056923619804e-18}));
+    S = dd_mul(f2, dd_add(S, NsDD{0.14285714285714285, 7.9301644616082606e-18}));
+    S = dd_mul(f2, dd_add(S, NsDD{0.20000000000000001, -1.1102230246251566e-17}));
+    S = dd_mul(f2, dd_add(S, NsDD{0.33333333333333331, 1.8503717077085941e-17}));
+    S = dd_add(S, NsDD{1.0, 0.0});
+    NsDD lnm = dd_mul(f, S);
+    lnm.hi *= 2.0;
+    lnm.lo *= 2.0;
+    /* e ln2, ln2 to 106 bits */
+    const double de = (double)e;
+    NsDD el = dd_two_prod(de, 0.69314718055994529);
+    el.lo += de * 2.3190468138462996e-17;
+    el = dd_fast_two_sum(el.hi, el.lo);
+    return dd_add(el, lnm);
+}
+/* the double nearest to ln x (correctly rounded but for ties closer than 2^-80) */
+__device__ __forceinline__ double ns_ln_cr(double x)
+{
+    const NsDD l = ns_ln_dd(x);
+    return l.hi + l.lo;
+}
+/* log10 x as glibc computes it (sysdeps/ieee754/dbl-64/e_log10.c, the fdlibm formula) with the correctly
+ * rounded log inside; x positive and normal */
+__device__ __forceinline__ double ns_log10_slow(double x)
+{
+    const double ivln10 = 4.34294481903251816668e-01, log10_2hi = 3.01029995663611771306e-01,
+                 log10_2lo = 3.69423907715893078616e-13;
+    const long long bits = __double_as_longlong(x);
+    const int k = (int)((bits >> 52) & 0x7ff) - 1023;
+    const int i = (k < 0) ? 1 : 0;
+    const double y = (double)(k + i);
+    const double xr = __longlong_as_double((bits & 0x000fffffffffffffLL) | ((long long)(0x3ff - i) << 52));
+    const double z = y * log10_2lo + ivln10 * ns_ln_cr(xr);
+    return z + y * log10_2hi;
+}
+
+/* the two sites, complete: fast log, guard, slow path.  *hit (optional) reports that the guard fired. */
+__device__ __forceinline__ float ns_vad_energy_expr(float frameSum, bool *hit = nullptr)
+{ /* NoiseSup.c:391 */
+    const double q = (double)frameSum / 64.0;
+    double v = 0.5 + (ns_ln(q) / kLn2) * 16.0;
+    const bool near = ns_near_float_boundary(v, 8);
+    if (hit) *hit = near;
+    if (__builtin_expect(near, 0)) v = 0.5 + (ns_ln_cr(q) / kLn2) * 16.0;
+    return (float)v;
+}
+__device__ __forceinline__ float ns_aversnr_expr(float averSNR, bool *hit = nullptr)
+{ /* NoiseSup.c:607; the caller has established (double)averSNR > 0.00001 */
+    double v = (20 * (ns_ln((double)averSNR) * 0.43429448190325182765)) / 3.0;
+    const bool near = ns_near_float_boundary(v, 16);
+    if (hit) *hit = near;
+    if (__builtin_expect(near, 0)) v = (20 * ns_log10_slow((double)averSNR)) / 3.0;
+    return (float)v;
+}
+
 /* FilterCalc (NoiseSup.c:449-563) for one PSD bin, in two pieces so that the pipelined kernel can
  * run them in different waves.  nb is the frame counter narrowed to int16 as the reference does
  * (SURVEY F9).
@@ -365,7 +507,7 @@ __device__ __forceinline__ float vad_frame_energy(float frameSum)
 #ifdef SEA_LIBM_LOG
     return uniform_f((float)(0.5 + (log((double)frameSum / 64.0) / kLn2) * 16.0));
 #else
-    return uniform_f((float)(0.5 + (ns_ln((double)frameSum / 64.0) / kLn2) * 16.0));
+    return uniform_f(ns_vad_energy_expr(frameSum));
 #endif
 }
 
@@ -423,8 +565,8 @@ __device__ __forceinline__ void gain_fact_update(NsRegs &s, float noiseEn)
     if ((double)averSNR > 0.00001)
 #ifdef SEA_LIBM_LOG
         averSNR = (float)((20 * log10((double)averSNR)) / 3.0);
-#else /* log10(y) = ln(y) * log10(e) */
-        averSNR = (float)((20 * (ns_ln((double)averSNR) * 0.43429448190325182765)) / 3.0);
+#else /* log10(y) = ln(y) * log10(e), guarded (ns_aversnr_expr) */
+        averSNR = ns_aversnr_expr(averSNR);
 #endif
     else
         averSNR = (float)(-100.0 / 3.0);

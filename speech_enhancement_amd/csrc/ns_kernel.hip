@@ -162,6 +162,68 @@ __global__ __launch_bounds__(256) void selftest_log_kernel(const float *x, doubl
     if (i < n) out[i] = ns_ln((double)x[i]);
 }
 
+/* the slow path's double-double logarithm on n doubles: hi + lo */
+__global__ __launch_bounds__(256) void selftest_log_dd_kernel(const double *x, double *hi, double *lo, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const NsDD l = ns_ln_dd(x[i]);
+        hi[i] = l.hi;
+        lo[i] = l.lo;
+    }
+}
+
+/* the two guarded call sites, complete (fast log, guard, slow path), on n floats: site1[i] = the VAD frame
+ * log-energy for frameSum = x[i] (x >= 64), site2[i] = averSNR for x[i] (x > 1e-5); NaN outside a site's range */
+__global__ __launch_bounds__(256) void selftest_log_sites_kernel(const float *x, float *site1, float *site2, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float v = x[i];
+        site1[i] = (v >= 64.0f) ? ns_vad_energy_expr(v) : __uint_as_float(0x7fc00000u);
+        site2[i] = ((double)v > 0.00001) ? ns_aversnr_expr(v) : __uint_as_float(0x7fc00000u);
+    }
+}
+
+/* EVERY float argument a site can see -- site 1: frameSum in [64, 2^37] (64 + 80 * 32768^2 = 2^36.3); site 2:
+ * every finite float above 1e-5 -- through the site's expression.  stats[0] = arguments, [1] = guard hits,
+ * [2] = hits where the slow path changed the float; the first `cap` hits are recorded as (argument, float of the
+ * fast log alone, float returned) so that the host can check them against an arbitrary-precision logarithm. */
+__global__ __launch_bounds__(256) void selftest_log_guard_kernel(int site, unsigned long long *stats, float *hits, int cap)
+{
+    const unsigned lo = (site == 1) ? 0x42800000u /* 64 */ : 0x3727C5ADu /* first float above 1e-5 (double compare) */;
+    const unsigned hi = (site == 1) ? 0x52000000u /* 2^37 */ : 0x7F7FFFFFu;
+    unsigned long long nhit = 0, nflip = 0, ntest = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long b = (unsigned long long)lo + blockIdx.x * blockDim.x + threadIdx.x; b <= hi; b += stride) {
+        const float x = __uint_as_float((unsigned)b);
+        if (site == 2 && !((double)x > 0.00001)) continue;
+        ntest++;
+        bool hit = false;
+        float got, fast;
+        if (site == 1) {
+            got = ns_vad_energy_expr(x, &hit);
+            fast = (float)(0.5 + (ns_ln((double)x / 64.0) / kLn2) * 16.0);
+        } else {
+            got = ns_aversnr_expr(x, &hit);
+            fast = (float)((20 * (ns_ln((double)x) * 0.43429448190325182765)) / 3.0);
+        }
+        if (hit) {
+            nhit++;
+            nflip += (__float_as_uint(got) != __float_as_uint(fast)) ? 1 : 0;
+            const unsigned long long slot = atomicAdd(stats + 3, 1ull);
+            if (slot < (unsigned long long)cap) {
+                hits[3 * slot + 0] = x;
+                hits[3 * slot + 1] = fast;
+                hits[3 * slot + 2] = got;
+            }
+        }
+    }
+    if (ntest) atomicAdd(stats + 0, ntest);
+    if (nhit) atomicAdd(stats + 1, nhit);
+    if (nflip) atomicAdd(stats + 2, nflip);
+}
+
 /* sea_selftest_nsdiv: ns_div / ns_inv64 (ns_core.h) against the compiler's IEEE division, bit for bit, on
  * pseudo-random and edge-mantissa operands spanning the whole domain ns_back() admits: denominators
  * 2^-30 .. 2^59, numerators 0 or 2^-76 .. 2^49 with an exponent difference within [-106, 80]; the double

@@ -110,6 +110,9 @@ __global__ void ns_stream_fd_kernel(NsStreamArgs a);
 __global__ void selftest_pi4_kernel(unsigned long long *mismatches);
 __global__ void selftest_dc_kernel(const float *dif, const float *y0, float *out, int *fellback, int ncases);
 __global__ void selftest_log_kernel(const float *x, double *out, int n);
+__global__ void selftest_log_dd_kernel(const double *x, double *hi, double *lo, int n);
+__global__ void selftest_log_sites_kernel(const float *x, float *site1, float *site2, int n);
+__global__ void selftest_log_guard_kernel(int site, unsigned long long *stats, float *hits, int cap);
 __global__ void selftest_nsdiv_kernel(unsigned long long *out, int iters);
 __global__ void selftest_div_kernel(const sea_gt_tables *t, unsigned long long *mismatches);
 __global__ void rfft256_kernel(const float *in, float *out, long long nframes, const sea_fft_tables *t);

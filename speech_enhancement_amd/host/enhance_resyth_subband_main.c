@@ -11,7 +11,10 @@
  *         <outputDictionary><save_noisy_dir><id>_noisy.wav
  *   out   <outputDictionary><save_resynth_e_dir><id>_e_resynth.wav
  *
- * Utterances are collected and resynthesised together on the GPU (one wavefront per utterance).
+ * Utterances are collected and resynthesised together on the GPU (one workgroup per utterance), CHUNK of
+ * them at a time: a chunk's WAVs are written and its buffers freed before the next chunk is read, so host
+ * memory stays bounded for lists of any length (configs[4]: 100 000 utterances); inside a chunk the library
+ * bounds its 256-B-per-sample HBM scratch by the free device memory (sea_resynth_utterances).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,12 +26,45 @@
 #ifndef SEA_IBM
 #define SEA_IBM 0
 #endif
+#ifndef CHUNK
+#define CHUNK 1024
+#endif
+
+/* resynthesise and write the n collected utterances, then free them */
+static int flush_chunk(const sea_cfg *opts, char **ids, const int *used, short **in, short **out, float **mask,
+                       long *len, int n, int dry, FILE *Log)
+{
+    char path[4 * SEA_FILE_LEN];
+    int rc = 0, u;
+    if (dry)
+        for (u = 0; u < n; u++) printf("  %s: %ld samples, %ld mask rows\n", ids[used[u]], len[u], (len[u] - 320) / 160 + 1);
+    if (!dry && n > 0) {
+        if (Log) fprintf(Log, "resynth\n ");
+        if (sea_resynth_utterances((const short *const *)in, len, (const float *const *)mask, SEA_IBM, out, n)) {
+            fprintf(stderr, "ERROR:   %s\n", sea_last_error());
+            rc = 1;
+        }
+        for (u = 0; u < n && !rc; u++) {
+            snprintf(path, sizeof path, "%s%s%s_e_resynth.wav", opts->outputDictionary, opts->save_resynth_e_dir,
+                     ids[used[u]]);
+            if (sea_wav_write(path, out[u], len[u], 16000)) rc = 4;
+        }
+    }
+    for (u = 0; u < n; u++) {
+        free(in[u]);
+        free(out[u]);
+        free(mask[u]);
+        in[u] = out[u] = NULL;
+        mask[u] = NULL;
+    }
+    return rc;
+}
 
 int main(int argc, char *argv[])
 {
     sea_cfg opts;
     char path[4 * SEA_FILE_LEN], buf[64 * 32], **ids = NULL;
-    int n_ids, dry, count = 0, rc = 0, row = 0, rows_needed = 0, cap = 0, n = 0, u;
+    int n_ids, dry, count = 0, rc = 0, row = 0, rows_needed = 0, cap = 0, n = 0;
     short **in = NULL, **out = NULL;
     float **mask = NULL;
     long *len = NULL;
@@ -50,23 +86,28 @@ int main(int argc, char *argv[])
         fprintf(stderr, "Open %s file error!\n", n_ids < 0 ? opts.purewavlist : path);
         return 2;
     }
-    while (fgets(buf, sizeof buf, erm)) {
+    cap = CHUNK;
+    in = (short **)calloc(cap, sizeof *in);
+    out = (short **)calloc(cap, sizeof *out);
+    mask = (float **)calloc(cap, sizeof *mask);
+    len = (long *)calloc(cap, sizeof *len);
+    used = (int *)calloc(cap, sizeof *used);
+    while (!rc && fgets(buf, sizeof buf, erm)) {
         if (strstr(buf, "[")) { /* next matrix -> next id of the list */
             int fs = 0;
             if (count >= n_ids) break;
-            if (n == cap) {
-                cap = cap ? 2 * cap : 256;
-                in = (short **)realloc(in, cap * sizeof *in);
-                out = (short **)realloc(out, cap * sizeof *out);
-                mask = (float **)realloc(mask, cap * sizeof *mask);
-                len = (long *)realloc(len, cap * sizeof *len);
-                used = (int *)realloc(used, cap * sizeof *used);
+            if (n == cap) { /* the chunk is full and its last matrix is complete: run it */
+                rc = flush_chunk(&opts, ids, used, in, out, mask, len, n, dry, Log);
+                n = 0;
+                if (rc) break;
             }
             printf("%s\n", ids[count]);
             if (Log) fprintf(Log, "%s\n ", ids[count]);
             snprintf(path, sizeof path, "%s%s%s_noisy.wav", opts.outputDictionary, opts.save_noisy_dir, ids[count]);
             if (sea_wav_read(path, &in[n], &len[n], &fs) || len[n] < 320) {
                 fprintf(stderr, "ERROR:   cannot use %s\n", path);
+                free(in[n]); /* a WAV shorter than one mask frame was read but is not kept */
+                in[n] = NULL;
                 rc = 3;
                 break;
             }
@@ -91,25 +132,10 @@ int main(int argc, char *argv[])
         }
     }
     fclose(erm);
-    if (dry)
-        for (u = 0; u < n; u++) printf("  %s: %ld samples, %ld mask rows\n", ids[used[u]], len[u], (len[u] - 320) / 160 + 1);
-    if (!dry && !rc && n > 0) {
-        if (Log) fprintf(Log, "resynth\n ");
-        if (sea_resynth_utterances((const short *const *)in, len, (const float *const *)mask, SEA_IBM, out, n)) {
-            fprintf(stderr, "ERROR:   %s\n", sea_last_error());
-            rc = 1;
-        }
-        for (u = 0; u < n && !rc; u++) {
-            snprintf(path, sizeof path, "%s%s%s_e_resynth.wav", opts.outputDictionary, opts.save_resynth_e_dir,
-                     ids[used[u]]);
-            if (sea_wav_write(path, out[u], len[u], 16000)) rc = 4;
-        }
-    }
-    for (u = 0; u < n; u++) {
-        free(in[u]);
-        free(out[u]);
-        free(mask[u]);
-    }
+    if (!rc)
+        rc = flush_chunk(&opts, ids, used, in, out, mask, len, n, dry, Log);
+    else
+        (void)flush_chunk(&opts, ids, used, in, out, mask, len, n, 1 /* free only */, NULL);
     free(in); free(out); free(mask); free(len); free(used);
     if (Log) fclose(Log);
     sea_free_list(ids, n_ids);

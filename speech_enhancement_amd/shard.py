@@ -4,7 +4,8 @@ Utterances are independent (the reference's only parallel harness is a thread po
 indices from a shared counter:
 function/20141106_speech_enhancement/aurora_speech_enhancement/aurora_speech_enhancement.cpp:111-121,
 311-327), so the data path needs NO collective: every rank denoises its own shard.  The only
-cross-rank data are the frame count (sum) and the timed region (max), reduced once at the end.
+cross-rank data are the frame count (sum) and the timed region (max), reduced once at the end
+on the host (gloo).
 """
 import numpy as np
 
@@ -31,12 +32,14 @@ def block_shard(n_utt, world, rank):
 
 
 def reduce_job(frames_local, seconds_local, dist=None, device=None):
-    """Whole-job aggregate: (total frames over all ranks, max seconds over ranks)."""
+    """Whole-job aggregate: (total frames over all ranks, max seconds over ranks).  Two scalars on
+    the HOST side of torch.distributed (gloo): the data path itself has no collective, so RCCL and
+    xGMI stay out of it entirely.  `device` is accepted for older callers and ignored."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return int(frames_local), float(seconds_local)
     import torch
-    f = torch.tensor([int(frames_local)], dtype=torch.int64, device=device)
-    t = torch.tensor([float(seconds_local)], dtype=torch.float64, device=device)
+    f = torch.tensor([int(frames_local)], dtype=torch.int64)
+    t = torch.tensor([float(seconds_local)], dtype=torch.float64)
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return int(f.item()), float(t.item())

@@ -49,6 +49,45 @@ def test_noisesup_1024_utterances_every_sample(shard, oracle):
     assert shard.n_frames == 817680
 
 
+def test_noisesup_configs4_shard_12500_utterances(oracle):
+    """configs[4]: one of the eight LPT shards of the 100 000-utterance corpus -- 12 500 utterances, ~10 M
+    frames, in ONE launch (48 utterances per CU: the large-batch kernel form).  A spread sample of 256
+    utterances bit-for-bit against the oracle; on ALL of them the frame indexing properties: first output
+    frame = onset + 4, nothing before it, and the shard's load within 0.1 % of the corpus mean."""
+    import torch
+    import bench
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    ids = bench.corpus_shard_ids(100000, 8, 0)
+    assert len(ids) == 12500
+    all_len = np.array([corpus.utterance_length(u) for u in range(100000)], dtype=np.int64)
+    assert abs(all_len[ids].sum() / (all_len.sum() / 8) - 1) < 1e-3
+    batch = bench.build_shard_ids(ids, torch.device("cuda", 0))
+    assert batch.n_frames == int(np.sum(all_len[ids] // 80))
+    out, _, first = sea.ns_denoise_batch(batch)
+    torch.cuda.synchronize()
+    host_in = batch.data.cpu().numpy()
+    host_out = out.cpu().numpy()
+    first = first.cpu().numpy()
+    pick = list(range(0, 12500, 49))[:256]
+    assert len(pick) == 256
+    utts = [host_in[batch.host_offsets[k]: batch.host_offsets[k] + batch.host_lengths[k]] for k in pick]
+    oracle.etsi_denoise(utts[0][:800])
+    with ThreadPoolExecutor(_threads()) as ex:
+        want = list(ex.map(oracle.etsi_denoise, utts))
+    bad = [k for k, w in zip(pick, want)
+           if not np.array_equal(host_out[batch.host_offsets[k]: batch.host_offsets[k] + batch.host_lengths[k]], w)]
+    assert not bad, f"{len(bad)} of 256 sampled utterances differ, first {bad[:5]}"
+    for k, u in enumerate(ids):
+        onset = 5 if u % 5 == 0 else 0
+        o = int(batch.host_offsets[k])
+        assert first[k] == onset + 4, (k, u, first[k])
+        assert not np.any(host_out[o: o + (onset + 4) * 80])
+        assert np.any(host_out[o + (onset + 4) * 80: o + (onset + 5) * 80])
+    del out, batch
+    torch.cuda.empty_cache()
+
+
 def test_noisesup_batch_composition_independence(shard):
     """An utterance's result does not depend on what else is in the batch or on launch order."""
     import torch

@@ -178,6 +178,66 @@ def test_sharding_world_size_2_gloo(tmp_path):
         assert p.returncode == 0, o
 
 
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher: the parent (which never touches torch or the GPU) starts two
+    rank processes, they meet over gloo and rank 0 prints ONE JSON line with n_gpus = 2 (--rehearse-cpu skips
+    the GPU work).  configs[4] mode: rank r takes LPT shard r of the 100 000-utterance corpus."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--utts", "16",
+                        "--rehearse-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    from speech_enhancement_amd import corpus
+    assert j["n_gpus"] == 2 and j["seconds_max"] == 2.0
+    assert j["total_frames"] == 3 * sum(corpus.utterance_length(u) // 80 for u in range(32))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--corpus-utts",
+                        "100000", "--rehearse-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["utterances_rank0"] == 12500 and j["n_gpus"] == 2
+    # the parent process of a real run must not have imported torch before spawning
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def run_rank")]
+    assert "\nimport torch" not in head.replace("    import torch", "")
+
+
+def test_bench_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "no GPU visible" in r.stderr and not r.stdout.strip()
+
+
+def test_integration_shim_compiles_against_the_reference_header(tmp_path):
+    """INTEGRATION.md section 2 shows the file a maintainer adds to the reference tree (etsi/cpp/SeaPlugin.c) to
+    install the engine into the FEParamsX vtable (etsi/cpp/ParmInterface.h:120-178).  Keep it compiling against
+    the reference's own header (this container only: /root/reference does not travel)."""
+    ref = "/root/reference/etsi/cpp"
+    if not os.path.exists(os.path.join(ref, "ParmInterface.h")):
+        pytest.skip("/root/reference absent")
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```c\n(/\* etsi/cpp/SeaPlugin\.c.*?)```", text, flags=re.S)
+    assert m, "SeaPlugin.c block not found in INTEGRATION.md"
+    src = tmp_path / "SeaPlugin.c"
+    src.write_text(m.group(1))
+    r = subprocess.run(["gcc", "-std=gnu99", "-Wall", "-Werror=implicit-function-declaration",
+                        "-Werror=incompatible-pointer-types", "-Werror=int-conversion", "-c", "-I", ref, "-I",
+                        os.path.join(ROOT, "include"), str(src), "-o", str(tmp_path / "SeaPlugin.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    nm = subprocess.run(["nm", str(tmp_path / "SeaPlugin.o")], capture_output=True, text=True).stdout
+    for sym in ("sea_ns_stream_alloc", "sea_ns_stream_init", "sea_ns_stream_push", "sea_ns_stream_delete",
+                "sea_compceps_frame", "AdvProcessAlloc"):
+        assert re.search(r"\bU " + sym + r"\b", nm), sym
+    assert re.search(r"\bT SeaAdvProcessAlloc\b", nm)
+
+
 def test_mask_text_format_roundtrip(tmp_path):
     """the Kaldi-style text matrix between feature extraction, the DNN and resynth
     (writer enhancement_extract_test/cpp/show_IBM.cpp:194-208, reader resyth_64sub_ori/cpp/main.cpp:
