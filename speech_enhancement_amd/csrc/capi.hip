@@ -371,7 +371,8 @@ int sea_compceps_frames(const float *d_data201, float *d_coef14, long long nfram
     if (nframes <= 0) return 0;
     DeviceCtx *c;
     if (ctx(&c)) return 1;
-    const long long grid = nframes < 65536 ? nframes : 65536;
+    const long long ntile = (nframes + 15) / 16; /* one wave per tile of 16 frames (cc_kernel.hip, kCcT) */
+    const long long grid = ntile < 8192 ? ntile : 8192;
     hipLaunchKernelGGL(sea::compceps_frames_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream,
                        d_data201, d_coef14, nframes, c->cc);
     HIP_TRY(hipGetLastError());
@@ -395,7 +396,8 @@ int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const
     a.n_ceps = d_n_ceps;
     a.tables = c->cc;
     a.n_utt = n_utt;
-    const long long grid = total_frames < 131072 ? total_frames : 131072;
+    const long long nslot = total_frames / 16 + n_utt; /* tile slots of 16 frames (cc_kernel.hip, kCcT) */
+    const long long grid = nslot < 8192 ? nslot : 8192;
     hipLaunchKernelGGL(sea::compceps_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -144,48 +144,242 @@ __device__ __forceinline__ void compceps_frame(const float *cur, float prev, flo
 
 } // namespace
 
+/* ==================================================================================================
+ * Tiled CompCeps: one wave owns a TILE of kCcT consecutive frames.
+ *
+ * The one-frame-per-wave form above spends most of its time on work that every one of its 64 lanes
+ * repeats: the frame's 200-term in-order energy sum (CompCeps.c:413-423) and its double-precision log.
+ * Here the tile's samples are staged in LDS once and
+ *   * the energy sums run LANE = FRAME (lane f adds the 200 squares of frame f in order; the hop
+ *     blocks sit 81 words apart -- one pad word per 80 samples -- so the 16 lanes hit 16 banks),
+ *     and the log of the sum is evaluated once per frame, again lane = frame;
+ *   * two frames at a time go through the dual transform (lanes 0..31 / 32..63, swizzled work area,
+ *     five LDS round trips instead of six), their power spectra and the 23 mel triangles (lane =
+ *     (frame, band));
+ *   * the 23 log energies of all frames are taken lane = (frame, band) flattened (6 evaluations of the
+ *     double log per tile instead of 16), the DCT lane = (frame, coefficient) flattened (4 passes).
+ * Arithmetic per value is compceps_frame()'s, operation by operation; only the distribution over
+ * lanes changes.  Zero-weight taps stand in for the band length test (acc + p * 0 == acc: p is a
+ * finite power, acc >= +0) and c0's plain sum is a DCT row of ones (x * 1.0f == x).
+ * ================================================================================================ */
+namespace {
+
+constexpr int kCcT = 16;
+
+template <bool SHARED>
+struct CcGeom {
+    /* SHARED: frames of one utterance, 80 samples apart, share their samples; word x of the span (x = 0 is
+     * Data[-1] of the tile's first frame) sits at x + x / 80.  Otherwise: kCcT separate frames of 201 floats. */
+    static constexpr int FS = SHARED ? 81 : 201;
+    static constexpr int SPAN = SHARED ? 81 * (kCcT - 1) + 204 : 201 * kCcT;
+};
+
+template <bool SHARED>
+struct __attribute__((aligned(16))) CcTileLds {
+    float span[(CcGeom<SHARED>::SPAN + 3) & ~3];
+    float work[512];
+    float pw[2][152];                 /* 129 power bins per frame, zeros behind (the mel taps read past 128) */
+    float fb[kCcT][24];
+    float dctT[SEA_CC_NCHAN * 16];
+    float outb[kCcT * SEA_CC_NCEP];
+};
+
+struct CcTileConst {
+    Fft2Regs fft;
+    float win8[8];
+    int qd[8], qm[8];                 /* word offsets of Data[idx], Data[idx-1] from the frame's base; qd < 0: idx >= 200 */
+    unsigned pa[4], nyq;              /* byte offsets in a work area: Re(l), Im(l), Re(l+64), Im(l+64); x[128] */
+    int melStart;
+    float melW[SEA_CC_TAPS];
+    float floorFB, floorE;
+};
+
+template <bool SHARED>
+__device__ __forceinline__ int cc_q(int x) /* word offset of Data[x-1] within its frame, x = 0..200 */
+{
+    return SHARED ? x + (x >= 80 ? 1 : 0) + (x >= 160 ? 1 : 0) : x;
+}
+
+template <bool SHARED>
+__device__ __forceinline__ void load_cc_tile_const(CcTileConst &C, CcTileLds<SHARED> &L, const sea_cc_tables *t, int lane)
+{
+    load_fft2_regs<false>(C.fft, &t->fft, lane, nullptr);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        constexpr int kRev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+        const int idx = (lane & 31) + 32 * kRev3[k];
+        C.win8[k] = t->win8[k][lane];
+        C.qd[k] = (idx < SEA_WIN) ? cc_q<SHARED>(idx + 1) : -1;
+        C.qm[k] = (idx < SEA_WIN) ? cc_q<SHARED>(idx) : 0;
+    }
+    C.pa[0] = fft_swz((unsigned)lane);
+    C.pa[1] = fft_swz((unsigned)(256 - lane) & 255u); /* lane 0: unused */
+    C.pa[2] = fft_swz((unsigned)lane + 64u);
+    C.pa[3] = fft_swz(192u - (unsigned)lane);
+    C.nyq = fft_swz(128u);
+    const int band = lane & 31;
+    C.melStart = (band < SEA_CC_NCHAN) ? t->melStart[band] : 0;
+#pragma unroll
+    for (int i = 0; i < SEA_CC_TAPS; ++i) C.melW[i] = (band < SEA_CC_NCHAN) ? t->melW[i][band] : 0.0f;
+    C.floorFB = t->floorFB;
+    C.floorE = t->floorE;
+    for (int i = lane; i < SEA_CC_NCHAN * 16; i += kLanes) L.dctT[i] = t->dctT[i >> 4][i & 15];
+    for (int i = lane; i < 2 * 152; i += kLanes) (&L.pw[0][0])[i] = 0.0f;
+    wave_sync();
+}
+
+/* the staged tile -> nv rows of 14 coefficients at dst */
+template <bool SHARED>
+__device__ __forceinline__ void cc_tile(CcTileLds<SHARED> &L, const CcTileConst &C, int nv, float *dst, int lane)
+{
+    constexpr int FS = CcGeom<SHARED>::FS;
+    /* logE (CompCeps.c:413-423): lane f sums the squares of frame f in sample order */
+    float logE; /* three ranges of the walk, each with a constant pad */
+    {
+        const float *p = L.span + FS * (lane & (kCcT - 1));
+        float acc = 0.0f;
+        if (lane < kCcT) {
+            if (SHARED) {
+#pragma unroll 8
+                for (int x = 1; x < 80; ++x) { const float v = p[x]; acc += v * v; }
+#pragma unroll 8
+                for (int x = 80; x < 160; ++x) { const float v = p[x + 1]; acc += v * v; }
+#pragma unroll 8
+                for (int x = 160; x < 201; ++x) { const float v = p[x + 2]; acc += v * v; }
+            } else {
+#pragma unroll 8
+                for (int x = 1; x < 201; ++x) { const float v = p[x]; acc += v * v; }
+            }
+        }
+        logE = (acc < C.floorE) ? (float)-50.0 : (float)log((double)acc);
+    }
+    const int npair = (nv + 1) >> 1;
+    for (int pr = 0; pr < npair; ++pr) {
+        const int h = lane >> 5;
+        const int f = 2 * pr + h;
+        const bool act = f < nv;
+        const float *p = L.span + FS * f;
+        /* pre-emphasis in double (:427-429), symmetric Hamming (:115-125), zero padding (:439-440) */
+        float e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = 0.0f;
+            if (act && C.qd[k] >= 0) {
+                const float d = p[C.qd[k]], dm1 = p[C.qm[k]];
+                v = (float)((double)d - 0.90 * (double)dm1) * C.win8[k];
+            }
+            e[k] = v;
+        }
+        rfft256_dual<false>(e, L.work, C.fft);
+        /* power spectrum, products and sum in double (:451-459), both frames */
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const float *w = L.work + 256 * hh;
+            const double r0 = (double)fft_at(w, C.pa[0]), r1 = (double)fft_at(w, C.pa[2]);
+            const double m0 = (lane > 0) ? (double)fft_at(w, C.pa[1]) : 0.0, m1 = (double)fft_at(w, C.pa[3]);
+            L.pw[hh][lane] = (lane > 0) ? (float)(r0 * r0 + m0 * m0) : (float)(r0 * r0);
+            L.pw[hh][lane + 64] = (float)(r1 * r1 + m1 * m1);
+            if (lane == 0) {
+                const double ny = (double)fft_at(w, C.nyq);
+                L.pw[hh][128] = (float)(ny * ny);
+            }
+        }
+        wave_sync();
+        /* 23 mel triangles (DoMelFB, MelProc.c:82-104): lane = (frame, band) */
+        {
+            const int band = lane & 31;
+            if (band < SEA_CC_NCHAN && act) {
+                const float *q = L.pw[h] + C.melStart;
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < SEA_CC_TAPS; ++i) acc = acc + q[i] * C.melW[i];
+                L.fb[f][band] = acc;
+            }
+        }
+        wave_sync();
+    }
+    /* natural log with floor (:509-513): lane = (frame, band) flattened */
+    for (int idx = lane; idx < nv * SEA_CC_NCHAN; idx += kLanes) {
+        const int f = idx / SEA_CC_NCHAN, b = idx - f * SEA_CC_NCHAN;
+        const float v = L.fb[f][b];
+        L.fb[f][b] = (v < C.floorFB) ? (float)-10.0 : (float)log((double)v);
+    }
+    wave_sync();
+    /* DCT (:203-227): lane = (frame, coefficient) flattened; c = 12 is c0, logE goes to c = 13 */
+    for (int idx = lane; idx < nv * 13; idx += kLanes) {
+        const int f = idx / 13, c = idx - f * 13;
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < SEA_CC_NCHAN; ++j) acc += L.fb[f][j] * L.dctT[j * 16 + c];
+        L.outb[f * SEA_CC_NCEP + c] = acc;
+    }
+    if (lane < nv) L.outb[lane * SEA_CC_NCEP + 13] = logE;
+    wave_sync();
+    for (int idx = lane; idx < nv * SEA_CC_NCEP; idx += kLanes) dst[idx] = L.outb[idx];
+    wave_sync();
+}
+
+} // namespace
+
 __global__ __launch_bounds__(64) void compceps_frames_kernel(const float *data201, float *coef14,
                                                              long long nframes, const sea_cc_tables *t)
 {
-    __shared__ CcLds L;
+    __shared__ CcTileLds<false> L;
     const int lane = threadIdx.x;
-    CcConst C;
-    load_cc_const(C, t, lane);
-    for (long long f = blockIdx.x; f < nframes; f += gridDim.x) {
-        const float *p = data201 + f * 201;
-        compceps_frame(p + 1, p[0], coef14 + f * SEA_CC_NCEP, L, C, lane);
+    CcTileConst C;
+    load_cc_tile_const<false>(C, L, t, lane);
+    const long long ntile = (nframes + kCcT - 1) / kCcT;
+    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const long long f0 = tile * kCcT;
+        const int nv = (int)((nframes - f0 < kCcT) ? nframes - f0 : kCcT);
+        const float *src = data201 + f0 * 201;
+        for (int i = lane; i < nv * 201; i += kLanes) L.span[i] = src[i];
+        wave_sync();
+        cc_tile<false>(L, C, nv, coef14 + f0 * SEA_CC_NCEP, lane);
     }
 }
 
 __global__ __launch_bounds__(64) void compceps_kernel(CepsArgs a)
 {
-    __shared__ CcLds L;
+    __shared__ CcTileLds<true> L;
     const int lane = threadIdx.x;
-    CcConst C;
-    load_cc_const(C, a.tables, lane);
-    const long long total = a.ceps_cum[a.n_utt];
-    for (long long g = blockIdx.x; g < total; g += gridDim.x) {
-        /* locate the utterance: largest u with ceps_cum[u] <= g */
-        int lo = 0, hi = a.n_utt;
+    CcTileConst C;
+    load_cc_tile_const<true>(C, L, a.tables, lane);
+    /* tile slots: utterance u owns slots [ceps_cum[u] / T + u, ceps_cum[u+1] / T + u + 1), at least
+     * ceil(capacity / T) of them; slot k of an utterance covers its cepstral frames kT .. kT + T - 1 */
+    const long long nslot = a.ceps_cum[a.n_utt] / kCcT + a.n_utt;
+    for (long long s = blockIdx.x; s < nslot; s += gridDim.x) {
+        int lo = 0, hi = a.n_utt; /* largest u with base(u) <= s */
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (a.ceps_cum[mid] <= g) lo = mid; else hi = mid;
+            if (a.ceps_cum[mid] / kCcT + mid <= s) lo = mid; else hi = mid;
         }
         const int u = lo;
-        const long long j = g - a.ceps_cum[u];
+        const long long c0 = a.ceps_cum[u], cap = a.ceps_cum[u + 1] - c0;
+        const long long j0 = (s - (c0 / kCcT + u)) * kCcT;
+        if (j0 >= cap) continue; /* spare slot */
         const int f0 = a.first_out[u];
         const long long nfr = a.lengths[u] / SEA_HOP;
         const long long nout = (f0 >= 0) ? nfr - f0 : 0;
         const long long nceps = (nout >= 3) ? nout - 2 : 0;
-        if (j == 0 && lane == 0 && a.n_ceps) a.n_ceps[u] = (int)nceps;
-        float *dst = a.ceps + g * SEA_CC_NCEP;
-        if (j < nceps) {
-            const float *cur = a.den_f32 + a.offsets[u] + (f0 + j) * SEA_HOP;
-            const float prev = (j == 0) ? 0.0f : cur[-1];
-            compceps_frame(cur, prev, dst, L, C, lane);
-        } else if (lane < SEA_CC_NCEP) {
-            dst[lane] = 0.0f;
+        if (j0 == 0 && lane == 0 && a.n_ceps) a.n_ceps[u] = (int)nceps;
+        const int nrow = (int)((cap - j0 < kCcT) ? cap - j0 : kCcT);
+        long long left = nceps - j0;
+        const int nv = (int)(left < 0 ? 0 : (left > nrow ? nrow : left));
+        float *dst = a.ceps + (c0 + j0) * SEA_CC_NCEP;
+        if (nv > 0) {
+            /* span word x = Data[x-1] of frame j0: the float NoiseSup stream from sample 80 (f0 + j0) - 1 on;
+             * Data[-1] of the utterance's very first cepstral frame is the zero before the first output */
+            const float *cur0 = a.den_f32 + a.offsets[u] + (f0 + j0) * SEA_HOP;
+            const int nword = SEA_HOP * (nv - 1) + SEA_WIN + 1;
+            for (int x = lane; x < nword; x += kLanes) {
+                const float v = (x == 0 && j0 == 0) ? 0.0f : cur0[x - 1];
+                L.span[x + x / SEA_HOP] = v;
+            }
+            wave_sync();
+            cc_tile<true>(L, C, nv, dst, lane);
         }
+        for (int idx = nv * SEA_CC_NCEP + lane; idx < nrow * SEA_CC_NCEP; idx += kLanes) dst[idx] = 0.0f;
     }
 }
 

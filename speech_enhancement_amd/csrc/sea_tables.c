@@ -335,6 +335,15 @@ void sea_build_cc_tables(sea_cc_tables *t)
             t->dct[j][i - 1] = (float)cos(kPi * (float)i / (float)SEA_CC_NCHAN * ((float)j + 0.5));
     t->floorFB = (float)exp((double)-10.0); /* CompCeps.c:405-406 */
     t->floorE = (float)exp((double)-50.0);
+    for (lane = 0; lane < SEA_LANES; lane++)
+        for (k = 0; k < 8; k++) {
+            i = (lane & 31) + 32 * (int)bitrev((unsigned)k, 3);
+            t->win8[k][lane] = (i < SEA_WIN) ? hamming_half(i < SEA_WIN / 2 ? i : SEA_WIN - 1 - i) : 0.0f;
+        }
+    for (j = 0; j < SEA_CC_NCHAN; j++) {
+        for (i = 0; i < 12; i++) t->dctT[j][i] = t->dct[j][i];
+        t->dctT[j][12] = 1.0f;
+    }
 }
 
 void sea_ns_plain_tables(float *sigWindow200, float *irWindow17, float *idct25x25, int *melStart25,

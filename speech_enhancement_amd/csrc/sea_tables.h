@@ -102,6 +102,10 @@ typedef struct {
     float dct[SEA_CC_NCHAN][SEA_LANES];           /* dct[j][i-1], lanes i-1 = 0..11 */
     float floorFB, floorE;                        /* (float)exp(-10.0), (float)exp(-50.0) */
     float pad[14];
+    /* the tiled kernels (cc_kernel.hip, cc_tile_*): two frames per wave through the dual transform */
+    float win8[8][SEA_LANES];                     /* Hamming(200)[(l & 31) + 32 * bitrev3(j)], 0 beyond 199 */
+    float dctT[SEA_CC_NCHAN][16];                 /* [j][c]: c = 0..11 the DCT rows of c1..c12, c = 12 all ones (c0 is
+                                                     the plain sum of the 23 log energies: x * 1.0f == x), 13..15 zero */
 } sea_cc_tables;
 
 typedef struct {
