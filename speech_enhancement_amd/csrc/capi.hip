@@ -283,8 +283,10 @@ int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
         hipLaunchKernelGGL(sea::ns_denoise_pipe6_kernel, dim3(n_utt), dim3(384), 0, (hipStream_t)stream, a);
     else if (form == 4)
         hipLaunchKernelGGL(sea::ns_denoise_pipe_big_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
-    else
+    else {
+        a.prio_row = (d_order && n_utt > c->n_cu) ? c->n_cu : 0; /* rows of the longest-first launch order */
         hipLaunchKernelGGL(sea::ns_denoise_pipe_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

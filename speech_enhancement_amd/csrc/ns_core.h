@@ -833,6 +833,21 @@ __device__ __forceinline__ void ns_idct_fir(float melOut, BackLds &B, const NsCo
     ns_fir_apply(B.fir, buf, dst, lane);
 }
 
+/* In-order sum over bins 0..64 of values that sit one per lane (bin 64 wave-uniform): each term arrives through
+ * v_readlane as a scalar operand, no LDS staging.  (Every 16 terms the source is made to depend on the running sum, or
+ * all 64 lane reads are hoisted and their SGPRs spill.)  A moving-accumulator form -- v_add_f32_dpp wave_shr:1, ONE
+ * instruction per term instead of two -- was measured 3.5 % slower end to end: its dependent chain is longer. */
+__device__ __forceinline__ float ns_lane_sum65(float vLo, float vHi)
+{
+    float total = 0.0f, src = vLo;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        if (k > 0 && (k & 15) == 0) asm("" : "+v"(src) : "v"(total));
+        total += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), k));
+    }
+    return total + vHi;
+}
+
 /* timing-only diagnostic (-DSEA_NS_TIMING -DSEA_NS_BACK_CK): shader clocks between checkpoints inside ns_back(),
  * accumulated by lane 0 of workgroup 0 in g_back_ck[ST * 8 + k]; read / reset through sea_debug_ns_back_ck().
  * Each checkpoint costs ~300 clk (s_memtime round trip), so the role totals of such a build are inflated. */
@@ -897,18 +912,7 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     const bool fast = SEA_NS_FAST_DIV && psdOk && noiseOk && (s.psdOk[ST] != 0);
     s.psdOk[ST] = psdOk ? 1 : 0;
     float WLo, WHi;
-    auto lane_sum = [&](float vLo, float vHi) {
-        /* in-order sum over bins 0..64 of values that sit one per lane: each term arrives through v_readlane
-         * as a scalar operand, no LDS staging.  (Every 16 terms the source is made to depend on the running
-         * sum, or all 64 lane reads are hoisted and their SGPRs spill.) */
-        float total = 0.0f, src = vLo;
-#pragma unroll
-        for (int k = 0; k < 64; ++k) {
-            if (k > 0 && (k & 15) == 0) asm("" : "+v"(src) : "v"(total));
-            total += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), k));
-        }
-        return total + vHi;
-    };
+    auto lane_sum = [&](float vLo, float vHi) { return ns_lane_sum65(vLo, vHi); };
     if (fast) {
         if (SEA_NS_PAIR_BINS && RL) { /* not in the 80-VGPR form: the pairs cost registers there (9 spills, -4 %) */
             filter_bins_fast<ST>(PLo, PHi, nSigLo, nSigHi, s.noiseLo[ST], s.noiseHi[ST], s.denLo[ST], s.denHi[ST],
@@ -1016,16 +1020,7 @@ __device__ __forceinline__ float ns_noise1(const float *psd, float *Pout, float 
         noiseOut[64] = s.noiseHi[1];
     }
     wave_sync();
-    float total = 0.0f; /* in-order sum of the noise spectrum through lane reads (see ns_back) */
-    {
-        float src = s.noiseLo[1];
-#pragma unroll
-        for (int k = 0; k < 64; ++k) {
-            if (k > 0 && (k & 15) == 0) asm("" : "+v"(src) : "v"(total));
-            total += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), k));
-        }
-        total += s.noiseHi[1];
-    }
+    const float total = ns_lane_sum65(s.noiseLo[1], s.noiseHi[1]); /* in-order sum of the noise spectrum */
     gain_fact_update(s, total);
     return s.alfaGF;
 }

@@ -687,15 +687,20 @@ def test_ns_large_batch_kernel_form(oracle):
 
 
 def test_ns_all_kernel_forms_agree(oracle):
-    """sea_ns_denoise_batch chooses among four forms of the same arithmetic by batch size (six waves
-    per utterance / four waves / four waves with less register use / one wave): forced one by one on
-    the mixed corpus, every form matches the oracle bit for bit."""
+    """sea_ns_denoise_batch chooses among four forms of the same arithmetic by batch size (six waves per
+    utterance / four waves / four waves with less register use / one wave): forced one by one on the mixed corpus
+    AND on the fill / drain corpus (0..12 frames, odd and even counts, 1..5 leading zero frames), every form
+    matches the oracle bit for bit -- int16 audio, float stream and the index of the first output frame."""
     import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
     torch = _torch()
     lib = sea.load()
     utts = _mixed_corpus()
+    utts += [corpus.synth_utterance(50 + n, 80 * n + (n * 13) % 80) for n in range(13)]
+    utts += [np.concatenate([np.zeros(80 * k, np.int16), corpus.synth_utterance(70 + k, 80 * (7 + k % 2))]) for k in (1, 2, 3, 4, 5)]
+    utts += [corpus.synth_utterance(90, 80 * 41), corpus.synth_utterance(91, 80 * 40 + 5)]
     batch = sea.PackedBatch.from_arrays(utts)
-    want = [oracle.etsi_denoise(x)[: len(x) // 80 * 80] for x in utts]
+    traces = [oracle.ns_trace(x, want_state=False) for x in utts]
     prev = lib.sea_ns_kernel_form(0)
     try:
         for form in (1, 2, 3, 4):
@@ -703,7 +708,15 @@ def test_ns_all_kernel_forms_agree(oracle):
             out, f32, first = sea.ns_denoise_batch(batch, want_f32=True)
             torch.cuda.synchronize()
             got = batch.split(out, full_frames_only=True)
-            for u in range(len(utts)):
-                assert np.array_equal(got[u], want[u]), f"form {form}, utterance {u}"
+            gotf = batch.split(f32, full_frames_only=True)
+            first_h = first.cpu().numpy()
+            for u, (x, tr) in enumerate(zip(utts, traces)):
+                nfr = len(x) // 80
+                assert np.array_equal(got[u], tr["out_i16"][: nfr * 80]), f"form {form}, utterance {u} (L={len(x)})"
+                assert int(first_h[u]) == (nfr - tr["nout"] if tr["nout"] else -1), f"form {form}, utterance {u}: first output"
+                if tr["nout"]:
+                    f0 = nfr - tr["nout"]
+                    assert np.array_equal(gotf[u][f0 * 80: nfr * 80].view(np.uint32), tr["den_f32"].view(np.uint32)), \
+                        f"form {form}, utterance {u}: float stream"
     finally:
         lib.sea_ns_kernel_form(prev)
