@@ -361,7 +361,8 @@ int sea_rfft256_batch(const float *d_in, float *d_out, long long nframes, void *
     if (nframes <= 0) return 0;
     DeviceCtx *c;
     if (ctx(&c)) return 1;
-    const long long grid = nframes < 65536 ? nframes : 65536;
+    const long long npair = (nframes + 1) / 2; /* one wave transforms two frames at a time */
+    const long long grid = npair < 16LL * c->n_cu ? npair : 16LL * c->n_cu;
     hipLaunchKernelGGL(sea::rfft256_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream, d_in,
                        d_out, nframes, &c->ns->fft);
     HIP_TRY(hipGetLastError());

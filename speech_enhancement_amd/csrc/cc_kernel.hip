@@ -15,23 +15,74 @@
 
 namespace sea {
 
-__global__ __launch_bounds__(64) void rfft256_kernel(const float *in, float *out, long long nframes,
-                                                     const sea_fft_tables *t)
+/* Streaming form: a wave transforms TWO frames at a time (lanes 0..31 / 32..63, the dual transform of
+ * sea_device.h: swizzled work area, five LDS round trips), 2 KB in + 2 KB out per pass.  Budget per frame at the
+ * HBM rate: ~240 clk per CU, i.e. ~960 SIMD-clk and ~240 LDS-array clk; the dual transform needs ~180 vector
+ * issue slots and ~144 LDS clk per frame (the one-frame-per-wave form: ~300 and ~320 -- LDS-bound).  Each lane
+ * gathers its eight inputs n0 + 32 bitrev3(j) straight from global memory (per instruction the 32 lanes of a frame
+ * read one contiguous 128-byte line), one pair ahead; results leave as one float4 per lane and frame. */
+#ifndef SEA_RFFT_ADDR_LDS
+#define SEA_RFFT_ADDR_LDS 0 /* operand addresses in VGPRs: 4.45 TB/s; in LDS (76 VGPRs, five waves per SIMD): 4.04 */
+#endif
+#ifndef SEA_RFFT_WAVES
+#define SEA_RFFT_WAVES 4
+#endif
+#ifndef SEA_RFFT_NT
+#define SEA_RFFT_NT 1
+#endif
+__global__ __launch_bounds__(64, SEA_RFFT_WAVES) void rfft256_kernel(const float *in, float *out, long long nframes,
+                                                                     const sea_fft_tables *t)
 {
-    __shared__ __attribute__((aligned(16))) float work[256];
+    __shared__ __attribute__((aligned(16))) float work[512];
+    __shared__ uint4 addrLds[SEA_RFFT_ADDR_LDS ? SEA_FFT_LSTAGES * 64 : 1];
     const int lane = threadIdx.x;
-    FftRegsSwz R; /* swizzled work area: no LDS bank conflicts in the butterflies */
-    load_fft_regs(R, t, lane);
-    for (long long f = blockIdx.x; f < nframes; f += gridDim.x) {
-        const float *x = in + f * 256;
-        rfft256(x[lane], x[lane + 64], x[lane + 128], x[lane + 192], work, R, lane);
-        float4 v; /* elements 4l..4l+3 of the reference's order, wherever the swizzle put them */
-        v.x = fft_at(work, fft_swz(4u * lane + 0u));
-        v.y = fft_at(work, fft_swz(4u * lane + 1u));
-        v.z = fft_at(work, fft_swz(4u * lane + 2u));
-        v.w = fft_at(work, fft_swz(4u * lane + 3u));
-        *reinterpret_cast<float4 *>(out + f * 256 + 4 * lane) = v;
+    Fft2Regs R;
+    load_fft2_regs<SEA_RFFT_ADDR_LDS != 0>(R, t, lane, addrLds);
+    wave_sync();
+    const int n0 = lane & 31, h = lane >> 5;
+    unsigned oa[4]; /* where elements 4l..4l+3 of the reference's order sit in a (swizzled) work area */
+#pragma unroll
+    for (int q = 0; q < 4; ++q) oa[q] = fft_swz(4u * (unsigned)lane + (unsigned)q);
+    const long long npair = (nframes + 1) >> 1;
+    auto load = [&](long long p, float(&e)[8]) {
+        const long long f = 2 * p + h;
+        const float *x = in + (f < nframes ? f : 0) * 256 + n0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            constexpr int kRev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+            const float v = SEA_RFFT_NT ? __builtin_nontemporal_load(x + 32 * kRev3[k]) : x[32 * kRev3[k]];
+            e[k] = (f < nframes) ? v : 0.0f;
+        }
+    };
+    float cur[8], nxt[8];
+    long long p = blockIdx.x;
+    if (p < npair) load(p, cur);
+    for (; p < npair; p += gridDim.x) {
+        const long long pn = p + gridDim.x;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) nxt[k] = 0.0f;
+        if (pn < npair) load(pn, nxt);
+        rfft256_dual<SEA_RFFT_ADDR_LDS != 0>(cur, work, R);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const long long f = 2 * p + hh;
+            if (f < nframes) {
+                const float *w = work + 256 * hh;
+                float4 v;
+                v.x = fft_at(w, oa[0]);
+                v.y = fft_at(w, oa[1]);
+                v.z = fft_at(w, oa[2]);
+                v.w = fft_at(w, oa[3]);
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                if (SEA_RFFT_NT)
+                    __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f *>(out + f * 256 + 4 * lane));
+                else
+                    *reinterpret_cast<float4 *>(out + f * 256 + 4 * lane) = v;
+            }
+        }
         wave_sync();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
     }
 }
 
