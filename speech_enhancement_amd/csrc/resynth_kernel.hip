@@ -402,16 +402,18 @@ __global__ __launch_bounds__(64) void gammatone_kernel(const float *in, float *o
 /* Synthesis pass: FOUR waves per utterance.
  *   R1  reads the stored tiles back to front (HBM), cascade stages 0-1
  *   R2  cascade stages 2-3 -> filter output g into a padded tile
- *   W   per step and channel: g / midEar, the mask-weighted raised-cosine overlap-add weight of that
- *       sample (at most two overlapping frames), their product, written back IN PLACE
- *   SUM lane = step: the 64 channel terms added in channel order (a 64-deep dependent chain, which
- *       is why it has a wave of its own), (short) cast, store
- * The g / product tile passes through three owners (R2, W, SUM), hence three buffers. */
+ *   W   per step and channel: the mask-weighted raised-cosine overlap-add weight of that sample (at most
+ *       two overlapping frames) times g / midEar, written back IN PLACE
+ *   SUM two jobs, because the 64-deep channel sum alone leaves this wave idle 60 % of a tile period while
+ *       W was the longest role: (1) lane = channel, g / midEar of the tile R2 has just finished, in place
+ *       (taken over from W: role timers W 2256 -> ~1700 clk per tile); (2) lane = step, the 64 channel
+ *       terms of the tile W finished added in channel order, (short) cast, store
+ * The tile passes through four owners (R2, division, W, sum), hence four buffers. */
 namespace {
 
 struct __attribute__((aligned(16))) BwdLds {
     v2f pq[2][kTile][64];             /* R1 -> R2 */
-    float gp[3][kTile * kTileStride]; /* R2 -> W -> SUM */
+    float gp[4][kTile * kTileStride]; /* R2 -> DIV -> W -> SUM: four owners, four buffers (tile & 3) */
     double olaUp[160], olaDown[160];
     float wbin[4][160]; /* binary masks: the only four weight curves there are (none | falling | rising | both) */
 };
@@ -423,7 +425,7 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
     v2f(*pq)[kTile][64] = S.pq;
     float(*gp)[kTile * kTileStride] = S.gp;
     double *olaUp = S.olaUp, *olaDown = S.olaDown;
-    const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 3;
+    const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 4;
     for (int i = threadIdx.x; i < 160; i += 256) {
         const double up = a.tables->olaUp[i], down = a.tables->olaDown[i];
         olaUp[i] = up;
@@ -505,17 +507,15 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
         const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
         const float gain = a.tables->gain[lane];
         GtHi s = {};
-        int buf = 0; /* (j-1) % 3 */
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
             const long long jt = j - 1;
             if (jt >= 0 && jt < ntile) {
                 const v2f(*i)[64] = pq[jt & 1];
-                float *o = gp[buf] + lane;
+                float *o = gp[jt & 3] + lane;
 #pragma unroll
                 for (int t = 0; t < kTile; ++t) o[t * kTileStride] = gt_step_hi(s, i[t][lane], C, gain);
             }
-            if (jt >= 0) buf = (buf == 2) ? 0 : buf + 1;
             RS_T_MID;
             tile_sync();
             RS_T_END;
@@ -525,7 +525,6 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
         /* mask rows: (L-320)/160+1, or L/160 with mode bit 1 (1dnn_resynth/extractwav.cpp:67) */
         const long long F = (a.binary & 2) ? L / 160 : (L - 320) / 160 + 1;
         const float *mask = a.mask + a.mask_offsets[u] * 64 + lane;
-        const DivConst ear = div_const(a.tables->midEar[lane]);
         const bool binary = (a.binary & 1) != 0;
         /* mask value of row h as the weight code sees it: the IBM variant turns > 0.5 into 1.0 and
          * skips everything else (resyth_64sub_IBM/cpp/extractwav.cpp:97-99); skipped == 0 here.
@@ -547,16 +546,14 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
         int r = (int)(mTop - h * 160);
         float mh = mask_val(mask_raw(h), h), mh1 = mask_val(mask_raw(h + 1), h + 1);
         float rawPrev = mask_raw(h - 1);
-        int buf = 0; /* (j-2) % 3 */
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
-            const long long jt = j - 2;
+            const long long jt = j - 3;
             if (jt >= 0 && jt < ntile) {
-                float *g = gp[buf] + lane;
-                float gv[kTile], v[kTile];
+                float *g = gp[jt & 3] + lane;
+                float v[kTile]; /* g / midEar (:89-90), left in place by the fourth wave one tile earlier */
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) gv[t] = g[t * kTileStride];
-                div_tile16(gv, v, ear); /* :89-90, the value landing on sample m */
+                for (int t = 0; t < kTile; ++t) v[t] = g[t * kTileStride];
                 if (r >= kTile - 1) {
                     /* whole tile inside one hop (9 tiles out of 10): branch-free, 16 independent
                      * steps for the scheduler.  float(double(0.0f) + x) == float(x), so the first
@@ -602,7 +599,6 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
                     }
                 }
             }
-            if (jt >= 0) buf = (buf == 2) ? 0 : buf + 1;
             RS_T_MID;
             tile_sync();
             RS_T_END;
@@ -611,14 +607,23 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
     } else {
         int16_t *out = a.out + off;
         const long long mTop = ntile * kTile - 1;
-        int buf = 0; /* (j-3) % 3 */
+        const DivConst ear = div_const(a.tables->midEar[lane]);
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
-            const long long jt = j - 3;
+            const long long jd = j - 2, jt = j - 4;
+            if (jd >= 0 && jd < ntile) { /* lane = channel: reverse[...] / midEar (:89-90) of the tile R2 finished, in place */
+                float *g = gp[jd & 3] + lane;
+                float gv[kTile], v[kTile];
+#pragma unroll
+                for (int t = 0; t < kTile; ++t) gv[t] = g[t * kTileStride];
+                div_tile16(gv, v, ear);
+#pragma unroll
+                for (int t = 0; t < kTile; ++t) g[t * kTileStride] = v[t];
+            }
             if (jt >= 0 && jt < ntile) {
                 if (lane < kTile) { /* channel sum in order 0..63 for step t = lane, (short) cast :120-121 */
                     const long long m = mTop - jt * kTile - lane;
-                    const float4 *row = reinterpret_cast<const float4 *>(gp[buf] + lane * kTileStride);
+                    const float4 *row = reinterpret_cast<const float4 *>(gp[jt & 3] + lane * kTileStride);
                     float acc = 0.0f;
 #pragma unroll
                     for (int c4 = 0; c4 < 16; ++c4) {
@@ -631,7 +636,6 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
                     if (m < L) out[m] = (int16_t)cast_i16(acc);
                 }
             }
-            if (jt >= 0) buf = (buf == 2) ? 0 : buf + 1;
             RS_T_MID;
             tile_sync();
             RS_T_END;
