@@ -147,6 +147,18 @@ int sea_resynth_utterances(const short *const *in, const long *lengths, const fl
 int sea_subband64(const short *in, long L, short *out);
 int sea_subband64_batch(const short *d_in, short *d_out, const long long *d_offsets, const long long *d_lengths,
                         const int *d_order, int n_utt, void *stream);
+/* SURVEY 8(f) #2 -- the ideal-ratio-mask TARGET of make_single_IBM (enhancement_extract_test/cpp/show_IBM.cpp:105-169):
+ * from the 64 subband streams of the clean and of the noise signal (two sea_subband64 outputs), frames of 320
+ * samples every 160, 512-point power spectrum, first 64 bins summed, IRM = pure / (pure + noise); one row of 64
+ * floats per frame = the mask matrix sea_resynth64 takes (and sea_mask_text_write prints).  The reference's
+ * spectrum routine, asdk::SpecInfo, is absent third-party code: its analysis window is the `window` parameter here
+ * (0 rectangular, 1 Hamming, 2 Hanning) and parity is unpinned.  Host form: streams [64][L], irm [F][64],
+ * F = (L-320)/160+1.  Batch form: blocks as sea_subband64_batch writes them; utterance u's rows start at
+ * d_row_offsets[u] (the d_mask_offsets of sea_resynth64_batch). */
+int sea_irm_target(const short *pure64, const short *noise64, long L, int window, float *irm);
+int sea_irm_target_batch(const short *d_pure64, const short *d_noise64, const long long *d_offsets,
+                         const long long *d_lengths, const long long *d_row_offsets, float *d_irm, int window,
+                         int n_utt, void *stream);
 /* gammaToneFilter(input, output, fChan, sigLength) for channel `chan` of the 64-band bank */
 int sea_gammatone_filter(const float *input, float *output, int chan, long sigLength);
 

@@ -167,6 +167,21 @@ class Oracle(_Lib):
             raise ValueError("ora_subband64: bad L")
         return out
 
+    def irm_target(self, pure64, noise64, window=1):
+        """make_single_IBM's IRM target from two [64][L] int16 subband blocks -> float32 [F][64]."""
+        pure64 = np.ascontiguousarray(pure64, dtype=np.int16)
+        noise64 = np.ascontiguousarray(noise64, dtype=np.int16)
+        assert pure64.shape == noise64.shape and pure64.shape[0] == 64
+        L = pure64.shape[1]
+        F = (L - 320) // 160 + 1
+        out = np.zeros((max(F, 1), 64), np.float32)
+        self.lib.ora_irm_target.restype = ctypes.c_int
+        rc = self.lib.ora_irm_target(_ptr(pure64), _ptr(noise64), ctypes.c_long(L), ctypes.c_long(L),
+                                     ctypes.c_int(window), _ptr(out))
+        if rc:
+            raise ValueError("ora_irm_target: bad L")
+        return out[:F]
+
     def resynth_channels(self):
         cf, bw, me = (np.zeros(64, np.float32) for _ in range(3))
         self.lib.ora_resynth_channels(_ptr(cf), _ptr(bw), _ptr(me))

@@ -229,3 +229,63 @@ int ora_subband64(const short *in, long L, short *out)
     free(h);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * SURVEY 8(f) rank 2 -- the ideal-ratio-mask TARGET of make_single_IBM
+ * (enhancement_extract_test/cpp/show_IBM.cpp:105-169): for each of the 64 subband streams of the clean and
+ * of the noise signal (the int16 outputs of subbband()), frames of WINDOW = 320 samples every OFFSET = 160,
+ * a 512-point power spectrum per frame (asdk::SpecInfo with m_nFFT = 512, :137-144), its first 64 bins
+ * summed in float in bin order (:154-158), IRM = sum_pure / (sum_pure + sum_noise) (:165).
+ *
+ * PARITY UNPINNED.  asdk::SpecInfo is third-party code that is neither in the reference tree nor in this
+ * image (version directory asdk_20130701; call sites show_IBM.cpp:41-43, :137-144) and no reference test or
+ * recorded output pins it, so what its GetSpecInfo does between "320 samples" and "power spectrum" -- the
+ * analysis window, a possible pre-emphasis or scaling -- is not known.  Restated here with the window as a
+ * parameter (0 rectangular, 1 Hamming 0.54 - 0.46 cos(2 pi n / 319), 2 Hanning 0.5 - 0.5 cos(2 pi n / 319);
+ * 1 is the default: SpecInfo is the front half of the SDK's MFCC extractor), zero padding to 512, an
+ * unnormalised |X|^2 (any constant factor cancels in the ratio).  The spectrum is evaluated as a direct DFT in
+ * double and rounded to float per bin.  pure / noise: [64][pitch] int16, irm: [F][64], F = (L-320)/160+1.
+ * ---------------------------------------------------------------------------------------- */
+static double irm_window(int kind, int n)
+{
+    if (kind == 1) return 0.54 - 0.46 * cos(2.0 * PI_HW * n / (WINDOW - 1));
+    if (kind == 2) return 0.5 - 0.5 * cos(2.0 * PI_HW * n / (WINDOW - 1));
+    return 1.0;
+}
+
+int ora_irm_target(const short *pure, const short *noise, long L, long pitch, int window, float *irm)
+{
+    long F, i;
+    int c, j, n;
+    static double cs[512], sn[512];
+    float w[WINDOW];
+    if (L < WINDOW || pitch < L) return 1;
+    F = (L - WINDOW) / OFFSET + 1;
+    for (n = 0; n < 512; n++) {
+        cs[n] = cos(2.0 * PI_HW * n / 512.0);
+        sn[n] = sin(2.0 * PI_HW * n / 512.0);
+    }
+    for (n = 0; n < WINDOW; n++) w[n] = (float)irm_window(window, n);
+    for (c = 0; c < NCHAN; c++)
+        for (i = 0; i < F; i++) {
+            float sum[2];
+            int which;
+            for (which = 0; which < 2; which++) {
+                const short *x = (which ? noise : pure) + (long)c * pitch + i * OFFSET;
+                float acc = 0.0f;
+                for (j = 0; j < NCHAN; j++) { /* bins 0..63 of the 512-point spectrum */
+                    double re = 0.0, im = 0.0;
+                    for (n = 0; n < WINDOW; n++) {
+                        const double v = (double)(w[n] * (float)x[n]);
+                        re += v * cs[(j * n) & 511];
+                        im -= v * sn[(j * n) & 511];
+                    }
+                    acc += (float)(re * re + im * im);
+                }
+                sum[which] = acc;
+            }
+            irm[i * NCHAN + c] = sum[0] / (sum[0] + sum[1]);
+        }
+    return 0;
+}
+

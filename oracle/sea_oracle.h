@@ -53,6 +53,10 @@ void ora_resynth_channels(float *cf64, float *bw64, float *midEar64);
  * hairCell resyth_64sub_ori/cpp/extractwav.cpp:212-257.  out is [64][L].  Parity unpinned. */
 void ora_haircell(const float *input, float *output, long L);
 int ora_subband64(const short *in, long L, short *out);
+/* SURVEY 8(f) rank 2 -- the IRM target of make_single_IBM (enhancement_extract_test/cpp/show_IBM.cpp:105-169) on
+ * the 64 subband streams of the clean and the noise signal ([64][pitch] int16 each); irm is [F][64],
+ * F = (L-320)/160+1; window 0 rectangular / 1 Hamming / 2 Hanning (asdk::SpecInfo is absent: parity unpinned). */
+int ora_irm_target(const short *pure, const short *noise, long L, long pitch, int window, float *irm);
 
 #ifdef __cplusplus
 }

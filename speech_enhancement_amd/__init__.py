@@ -14,6 +14,6 @@ Only what that path needs lives here:
 from . import corpus  # noqa: F401
 from ._lib import LIB_PATH, SeaError, load  # noqa: F401
 from .engine import (DoCompCeps, MaskBatch, NoiseSup, PackedBatch, afe_features_batch, compceps_batch,  # noqa: F401
-                     compceps_frames, etsi_denoise, gammaToneFilter, ns_denoise_batch,
+                     compceps_frames, etsi_denoise, gammaToneFilter, irm_target, irm_target_batch, ns_denoise_batch,
                      ns_streams_push, resynth, resynth_batch, resynth_scratch_elems, rfft, rfft_batch, subband_batch, subbband,
                      tables)

@@ -41,6 +41,8 @@ PROTOTYPES = {
     "sea_resynth_utterances": (_i, [_vp, _vp, _vp, _i, _vp, _i]),
     "sea_subband64": (_i, [_vp, _l, _vp]),
     "sea_subband64_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "sea_irm_target": (_i, [_vp, _vp, _l, _i, _vp]),
+    "sea_irm_target_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "sea_gammatone_filter": (_i, [_vp, _vp, _i, _l]),
     "sea_ns_stream_alloc": (_vp, []),
     "sea_ns_stream_init": (None, [_vp]),

@@ -698,6 +698,51 @@ int sea_subband64(const short *in, long L, short *out)
     return 0;
 }
 
+int sea_irm_target_batch(const short *d_pure64, const short *d_noise64, const long long *d_offsets, const long long *d_lengths,
+                         const long long *d_row_offsets, float *d_irm, int window, int n_utt, void *stream)
+{
+    if (n_utt <= 0) return 0;
+    if (window < 0 || window > 2) return fail("irm_target: window %d (0 rectangular, 1 Hamming, 2 Hanning)", window);
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    sea::IrmArgs a;
+    a.pure = d_pure64;
+    a.noise = d_noise64;
+    a.offsets = d_offsets;
+    a.lengths = d_lengths;
+    a.row_offsets = d_row_offsets;
+    a.irm = d_irm;
+    a.fft = &c->ns->fft;
+    a.n_utt = n_utt;
+    a.window = window;
+    hipLaunchKernelGGL(sea::irm_target_kernel, dim3((unsigned)n_utt * 64u), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sea_irm_target(const short *pure64, const short *noise64, long L, int window, float *irm)
+{
+    if (L < 320) return fail("irm_target: L=%ld is shorter than one 320-sample frame", L);
+    const long long Lp = align8(L), F = (L - 320) / 160 + 1;
+    DevBuf<short> dp, dn;
+    DevBuf<float> dirm;
+    DevBuf<long long> dmeta;
+    HIP_TRY(dp.alloc((size_t)Lp * 64));
+    HIP_TRY(dn.alloc((size_t)Lp * 64));
+    HIP_TRY(dirm.alloc((size_t)F * 64));
+    HIP_TRY(dmeta.alloc(3));
+    const long long meta[3] = {0, L, 0};
+    HIP_TRY(hipMemcpy2D(dp.p, (size_t)Lp * sizeof(short), pure64, (size_t)L * sizeof(short), (size_t)L * sizeof(short), 64,
+                        hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy2D(dn.p, (size_t)Lp * sizeof(short), noise64, (size_t)L * sizeof(short), (size_t)L * sizeof(short), 64,
+                        hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dmeta.p, meta, sizeof meta, hipMemcpyHostToDevice));
+    if (sea_irm_target_batch(dp.p, dn.p, dmeta.p, dmeta.p + 1, dmeta.p + 2, dirm.p, window, 1, nullptr)) return 1;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(irm, dirm.p, (size_t)F * 64 * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int sea_gammatone_filter(const float *input, float *output, int chan, long sigLength)
 {
     if (chan < 0 || chan >= 64) return fail("gammatone: channel %d out of range", chan);

@@ -99,6 +99,19 @@ struct SubbandArgs {
     int n_utt;
 };
 
+/* IRM target from the subband streams of the clean and the noise signal (irm_kernel.hip) */
+struct IrmArgs {
+    const int16_t *pure, *noise;   /* [64][pitch] blocks at offsets[u] * 64, pitch = lengths[u] rounded up to 8 */
+    const long long *offsets;
+    const long long *lengths;
+    const long long *row_offsets;  /* first mask row of utterance u; rows = (lengths[u] - 320) / 160 + 1 */
+    float *irm;                    /* [rows][64] */
+    const sea_fft_tables *fft;
+    int n_utt;
+    int window;                    /* 0 rectangular, 1 Hamming, 2 Hanning */
+};
+__global__ void irm_target_kernel(IrmArgs a);
+
 __global__ void subband_kernel(SubbandArgs a);
 __global__ void ns_denoise_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_kernel(NsBatchArgs a);

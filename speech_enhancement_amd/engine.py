@@ -79,6 +79,21 @@ def subbband(x):
     return out
 
 
+def irm_target(pure64, noise64, window=1):
+    """make_single_IBM's IRM target (enhancement_extract_test/cpp/show_IBM.cpp:105-169) from the [64][L] int16
+    subband blocks of the clean and the noise signal (two subbband() outputs) -> float32 [F][64], the mask matrix
+    resynth() takes.  window: 0 rectangular, 1 Hamming, 2 Hanning (asdk::SpecInfo's is unknown: parity unpinned)."""
+    lib = _lib.load()
+    pure64 = np.ascontiguousarray(pure64, dtype=np.int16)
+    noise64 = np.ascontiguousarray(noise64, dtype=np.int16)
+    if pure64.shape != noise64.shape or pure64.ndim != 2 or pure64.shape[0] != 64:
+        raise ValueError("irm_target needs two [64][L] int16 blocks")
+    L = pure64.shape[1]
+    out = np.zeros((max((L - 320) // 160 + 1, 1), 64), np.float32)
+    _lib.check(lib.sea_irm_target(_np_ptr(pure64), _np_ptr(noise64), L, int(window), _np_ptr(out)), "irm_target")
+    return out
+
+
 def gammaToneFilter(x, chan):
     lib = _lib.load()
     x = np.ascontiguousarray(x, dtype=np.float32)
@@ -383,6 +398,24 @@ def subband_batch(batch, out=None, use_order=True):
                                  _dptr(batch.order) if use_order else None, batch.n_utt, _stream_ptr())
     _lib.check(rc, "sea_subband64_batch")
     return out
+
+
+def irm_target_batch(batch, pure_sub, noise_sub, window=1):
+    """IRM target of every utterance of the batch from two subband_batch() outputs (clean, noise).  Returns a
+    MaskBatch (rows (L_u - 320) / 160 + 1 per utterance) that resynth_batch() takes as it is."""
+    torch = _torch()
+    lib = _lib.load()
+    if np.any(np.asarray(batch.host_lengths) < 320):
+        raise ValueError("irm_target needs utterances of at least one 320-sample frame")
+    rows = (np.asarray(batch.host_lengths) - 320) // 160 + 1
+    offs = np.concatenate(([0], np.cumsum(rows)[:-1])).astype(np.int64)
+    dev = batch.data.device
+    irm = torch.zeros((int(rows.sum()), 64), dtype=torch.float32, device=dev)
+    d_offs = torch.from_numpy(offs).to(dev)
+    _lib.check(lib.sea_irm_target_batch(_dptr(pure_sub), _dptr(noise_sub), _dptr(batch.offsets), _dptr(batch.lengths),
+                                        _dptr(d_offs), _dptr(irm), int(window), batch.n_utt, _stream_ptr()),
+               "sea_irm_target_batch")
+    return MaskBatch(irm, d_offs, offs, rows)
 
 
 def ns_streams_push(frames, state=None, reset=None, want_flags=False):

@@ -470,6 +470,44 @@ def test_subband_vs_oracle(oracle):
     assert one.min() >= 0 and one.max() > 100      # hair-cell output is a non-negative firing rate
 
 
+def test_irm_target_vs_oracle(oracle):
+    """the IRM target of make_single_IBM on the subband streams of a clean and a noise signal
+    (both produced by subbband() on the GPU).  Parity unpinned (asdk::SpecInfo is absent); the GPU's float
+    transform against the oracle's double-precision DFT of the same definition: |delta| <= 1e-4, values in [0, 1],
+    identical streams -> 0.5 exactly, host and batch entry points agree, the result drives resynth()."""
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    torch = _torch()
+    lens = [4800, 320, 320 + 160 * 3 + 11]
+    clean = [corpus.synth_utterance(120 + i, L) for i, L in enumerate(lens)]
+    noise = [(corpus.synth_utterance(140 + i, L).astype(np.int32) // 3).astype(np.int16) for i, L in enumerate(lens)]
+    cb, nb = sea.PackedBatch.from_arrays(clean), sea.PackedBatch.from_arrays(noise)
+    cs, ns = sea.subband_batch(cb), sea.subband_batch(nb)
+    worst = 0.0
+    for window in (1, 0, 2):
+        mb = sea.irm_target_batch(cb, cs, ns, window)
+        torch.cuda.synchronize()
+        got_all = mb.data.cpu().numpy()
+        for u, L in enumerate(lens):
+            want = oracle.irm_target(oracle.subband64(clean[u]), oracle.subband64(noise[u]), window)
+            got = got_all[mb.host_row_offsets[u]: mb.host_row_offsets[u] + mb.host_rows[u]]
+            assert got.shape == want.shape == ((L - 320) // 160 + 1, 64)
+            ok = ~np.isnan(want)
+            assert np.array_equal(np.isnan(got), ~ok)
+            worst = max(worst, float(np.abs(got[ok] - want[ok]).max()))
+            assert got[ok].min() >= 0.0 and got[ok].max() <= 1.0
+    print("IRM target max |delta| vs the oracle:", worst)
+    assert worst <= 1e-4
+    one = sea.irm_target(oracle.subband64(clean[0]), oracle.subband64(noise[0]))
+    assert np.abs(one - oracle.irm_target(oracle.subband64(clean[0]), oracle.subband64(noise[0]))).max() <= 1e-4
+    same = sea.irm_target(oracle.subband64(clean[0]), oracle.subband64(clean[0]))
+    assert np.all(same[~np.isnan(same)] == np.float32(0.5))
+    # the mask drives the resynthesis of the noisy mixture
+    mix = (clean[0].astype(np.int32) + noise[0]).clip(-32768, 32767).astype(np.int16)
+    y = sea.resynth(mix, one)
+    assert np.array_equal(y, oracle.resynth64(mix, one))
+
+
 def _float_stream_case(seed, nfr=60):
     rng = np.random.default_rng(seed)
     t = np.arange(nfr * 80)
