@@ -212,12 +212,14 @@ int sea_selftest_log(const float *x, double *ln_out, int n);
  *   sea_selftest_log_dd     the double-double log itself on n doubles (host pointers): hi + lo
  *   sea_selftest_log_sites  both complete sites on n floats: site1 = VAD frame log-energy of frameSum = x
  *                           (x >= 64), site2 = averSNR of x (x > 1e-5); NaN outside a site's range
- *   sea_selftest_log_guard  sweeps EVERY float argument of site 1 ([64, 2^37]) or 2 (every float > 1e-5):
- *                           stats4 = {arguments, guard hits, hits where the slow path changed the float, hits
- *                           recorded}; hits3 receives up to cap triples (argument, fast float, returned float) */
+ *   sea_selftest_log_guard  sweeps EVERY float argument of site 1 ([64, 2^37]) or 2 (every float > 1e-5) through
+ *                           the fast AND the slow form: stats8 = {arguments, guard hits, hits where the slow form
+ *                           changed the float, hits recorded, arguments outside the guard window on which the two
+ *                           forms disagree (must be 0), 0, 0, 0}; hits3 receives up to cap triples (argument, fast
+ *                           float, returned float) */
 int sea_selftest_log_dd(const double *x, double *hi, double *lo, int n);
 int sea_selftest_log_sites(const float *x, float *site1, float *site2, int n);
-int sea_selftest_log_guard(int site, unsigned long long *stats4, float *hits3, int cap);
+int sea_selftest_log_guard(int site, unsigned long long *stats8, float *hits3, int cap);
 
 #ifdef __cplusplus
 }

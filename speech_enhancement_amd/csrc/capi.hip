@@ -989,7 +989,7 @@ int sea_selftest_log_sites(const float *x, float *site1, float *site2, int n)
     return 0;
 }
 
-int sea_selftest_log_guard(int site, unsigned long long *stats4, float *hits3, int cap)
+int sea_selftest_log_guard(int site, unsigned long long *stats8, float *hits3, int cap)
 {
     if (site != 1 && site != 2) return fail("selftest_log_guard: site must be 1 or 2");
     if (cap < 0) cap = 0;
@@ -997,14 +997,14 @@ int sea_selftest_log_guard(int site, unsigned long long *stats4, float *hits3, i
     if (ctx(&c)) return 1;
     DevBuf<unsigned long long> ds;
     DevBuf<float> dh;
-    HIP_TRY(ds.alloc(4));
+    HIP_TRY(ds.alloc(8));
     HIP_TRY(dh.alloc((size_t)3 * (cap > 0 ? cap : 1)));
-    HIP_TRY(hipMemset(ds.p, 0, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ds.p, 0, 8 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(dh.p, 0, (size_t)3 * (cap > 0 ? cap : 1) * sizeof(float)));
     hipLaunchKernelGGL(sea::selftest_log_guard_kernel, dim3(4096), dim3(256), 0, nullptr, site, ds.p, dh.p, cap);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(stats4, ds.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(stats8, ds.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     if (cap > 0 && hits3) HIP_TRY(hipMemcpy(hits3, dh.p, (size_t)3 * cap * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }

@@ -158,8 +158,8 @@ __device__ __forceinline__ double ns_ln(double x)
  * only differ when the double expression lands within a few double ulps of a float ROUNDING BOUNDARY (the low 29
  * bits of its significand = 2^28).  ns_near_float_boundary() tests exactly that, with a window K that covers
  * both logs' error bounds propagated through the expression (site 1: 1.21 ulp of the log -> <= 4.4 ulp of the
- * result, K = 8; site 2: 4.5 ulp -> <= 13, K = 16).  Inside the window (probability (2K+1) 2^-29 per call:
- * 3e-8 / 6e-8) the logarithm is recomputed in double-double arithmetic, accurate to 2^-80, and rounded once --
+ * result, + 1.5 for the folded constants, K = 10; site 2: 4.5 ulp -> <= 13, + 1.5, K = 20).  Inside the window
+ * (probability (2K+1) 2^-29 per call: 4e-8 / 8e-8) the logarithm is recomputed in double-double arithmetic, accurate to 2^-80, and rounded once --
  * the correctly rounded value, which is what glibc's log returns in all but ~4 % of such cases; at site 2 it is
  * put through the very formula glibc's log10 uses (fdlibm e_log10.c:  z = k log10_2lo + ivln10 log(x'),
  * z + k log10_2hi, verified equal to this image's log10 on 2 M arguments).  What remains is the reference libm's own
@@ -275,22 +275,35 @@ __device__ __forceinline__ double ns_log10_slow(double x)
     return z + y * log10_2hi;
 }
 
-/* the two sites, complete: fast log, guard, slow path.  *hit (optional) reports that the guard fired. */
+/* the two sites, complete: fast log, guard, slow path.  *hit (optional) reports that the guard fired.
+ * The fast forms also fold the expression's constant divisions into ONE multiplication -- (L / ln2) * 16 = L * (16 / ln2),
+ * (20 L log10e) / 3 = L * (20 log10e / 3): each differs from the reference's operation sequence by at most ~1.5 ulp
+ * of the double result, which the guard windows (K = 10 / 20 double ulps around a float rounding boundary) cover
+ * together with the logs' own error bounds; a double division is a ~15-instruction dependent chain on the two
+ * longest role waves.  The slow forms keep the reference's literal operations.  sea_selftest_log_guard() runs BOTH
+ * forms on every float argument and counts disagreements outside the window (none). */
+__device__ __forceinline__ float ns_vad_energy_slow(float frameSum)
+{
+    return (float)(0.5 + (ns_ln_cr((double)frameSum / 64.0) / kLn2) * 16.0);
+}
 __device__ __forceinline__ float ns_vad_energy_expr(float frameSum, bool *hit = nullptr)
 { /* NoiseSup.c:391 */
-    const double q = (double)frameSum / 64.0;
-    double v = 0.5 + (ns_ln(q) / kLn2) * 16.0;
-    const bool near = ns_near_float_boundary(v, 8);
+    const double v = __fma_rn(ns_ln((double)frameSum * 0.015625), 23.083120654223414 /* 16 / ln 2 */, 0.5);
+    const bool near = ns_near_float_boundary(v, 10);
     if (hit) *hit = near;
-    if (__builtin_expect(near, 0)) v = 0.5 + (ns_ln_cr(q) / kLn2) * 16.0;
+    if (__builtin_expect(near, 0)) return ns_vad_energy_slow(frameSum);
     return (float)v;
+}
+__device__ __forceinline__ float ns_aversnr_slow(float averSNR)
+{
+    return (float)((20 * ns_log10_slow((double)averSNR)) / 3.0);
 }
 __device__ __forceinline__ float ns_aversnr_expr(float averSNR, bool *hit = nullptr)
 { /* NoiseSup.c:607; the caller has established (double)averSNR > 0.00001 */
-    double v = (20 * (ns_ln((double)averSNR) * 0.43429448190325182765)) / 3.0;
-    const bool near = ns_near_float_boundary(v, 16);
+    const double v = ns_ln((double)averSNR) * 2.8952965460216789 /* 20 log10(e) / 3 */;
+    const bool near = ns_near_float_boundary(v, 20);
     if (hit) *hit = near;
-    if (__builtin_expect(near, 0)) v = (20 * ns_log10_slow((double)averSNR)) / 3.0;
+    if (__builtin_expect(near, 0)) return ns_aversnr_slow(averSNR);
     return (float)v;
 }
 

@@ -186,27 +186,31 @@ __global__ __launch_bounds__(256) void selftest_log_sites_kernel(const float *x,
 }
 
 /* EVERY float argument a site can see -- site 1: frameSum in [64, 2^37] (64 + 80 * 32768^2 = 2^36.3); site 2:
- * every finite float above 1e-5 -- through the site's expression.  stats[0] = arguments, [1] = guard hits,
- * [2] = hits where the slow path changed the float; the first `cap` hits are recorded as (argument, float of the
- * fast log alone, float returned) so that the host can check them against an arbitrary-precision logarithm. */
+ * every finite float above 1e-5 -- through the site's fast form AND its slow form (double-double log, the
+ * reference's literal operation sequence).  stats[0] = arguments, [1] = guard hits, [2] = hits where the slow
+ * form changed the float, [3] = hits recorded, [4] = arguments OUTSIDE the guard window on which the two forms
+ * disagree (must be 0: that is the guard's claim); the first `cap` hits are recorded as (argument, float of the
+ * fast form alone, float returned) so that the host can check them against an arbitrary-precision logarithm. */
 __global__ __launch_bounds__(256) void selftest_log_guard_kernel(int site, unsigned long long *stats, float *hits, int cap)
 {
     const unsigned lo = (site == 1) ? 0x42800000u /* 64 */ : 0x3727C5ADu /* first float above 1e-5 (double compare) */;
     const unsigned hi = (site == 1) ? 0x52000000u /* 2^37 */ : 0x7F7FFFFFu;
-    unsigned long long nhit = 0, nflip = 0, ntest = 0;
+    unsigned long long nhit = 0, nflip = 0, ntest = 0, nmiss = 0;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long b = (unsigned long long)lo + blockIdx.x * blockDim.x + threadIdx.x; b <= hi; b += stride) {
         const float x = __uint_as_float((unsigned)b);
         if (site == 2 && !((double)x > 0.00001)) continue;
         ntest++;
         bool hit = false;
-        float got, fast;
+        float got, fast, slow;
         if (site == 1) {
             got = ns_vad_energy_expr(x, &hit);
-            fast = (float)(0.5 + (ns_ln((double)x / 64.0) / kLn2) * 16.0);
+            fast = (float)__fma_rn(ns_ln((double)x * 0.015625), 23.083120654223414, 0.5);
+            slow = ns_vad_energy_slow(x);
         } else {
             got = ns_aversnr_expr(x, &hit);
-            fast = (float)((20 * (ns_ln((double)x) * 0.43429448190325182765)) / 3.0);
+            fast = (float)(ns_ln((double)x) * 2.8952965460216789);
+            slow = ns_aversnr_slow(x);
         }
         if (hit) {
             nhit++;
@@ -217,11 +221,13 @@ __global__ __launch_bounds__(256) void selftest_log_guard_kernel(int site, unsig
                 hits[3 * slot + 1] = fast;
                 hits[3 * slot + 2] = got;
             }
-        }
+        } else
+            nmiss += (__float_as_uint(got) != __float_as_uint(slow)) ? 1 : 0;
     }
     if (ntest) atomicAdd(stats + 0, ntest);
     if (nhit) atomicAdd(stats + 1, nhit);
     if (nflip) atomicAdd(stats + 2, nflip);
+    if (nmiss) atomicAdd(stats + 4, nmiss);
 }
 
 /* sea_selftest_nsdiv: ns_div / ns_inv64 (ns_core.h) against the compiler's IEEE division, bit for bit, on

@@ -420,13 +420,15 @@ def test_selftest_log_guard_sweep(site):
     import speech_enhancement_amd as sea
     _torch()
     cap = 4096
-    stats = np.zeros(4, np.uint64)
+    stats = np.zeros(8, np.uint64)
     hits = np.zeros((cap, 3), np.float32)
     assert sea.load().sea_selftest_log_guard(site, stats.ctypes.data, hits.ctypes.data, cap) == 0
-    n, nhit, nflip, nrec = (int(v) for v in stats)
-    print(f"site {site}: {n} arguments, {nhit} guard hits ({nhit / n:.2e} per call), slow path changed {nflip} floats")
+    n, nhit, nflip, nrec, nmiss = (int(v) for v in stats[:5])
+    print(f"site {site}: {n} arguments, {nhit} guard hits ({nhit / n:.2e} per call), slow path changed {nflip} floats, "
+          f"fast != slow outside the guard window: {nmiss}")
     assert n == (0x52000000 - 0x42800000 + 1 if site == 1 else 0x7F7FFFFF - 0x3727C5AD + 1)
-    window = 17 if site == 1 else 33
+    assert nmiss == 0, "the guard window does not cover the fast form's error"
+    window = 21 if site == 1 else 41
     assert 0 < nhit < 4 * window * n / 2 ** 29 + 20 and nrec == nhit and nhit <= cap
     bad_cr = libm_differs_fast = libm_differs_final = 0
     for x, fast, got in hits[:nhit]:
