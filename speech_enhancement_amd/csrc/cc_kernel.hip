@@ -1,7 +1,7 @@
 /*
  * cc_kernel.hip -- batched rfft and the CompCeps cepstral front-end, gfx950 (MI355X).
  *
- * Both are recursion-free per frame, so the launch is one 64-lane wavefront per frame.
+ * Both are recursion-free per frame: a wave takes two frames (rfft) or a tile of 16 frames (CompCeps) at a time.
  *   rfft256_kernel           etsi/cpp/rfft.c:45-180 on [nframes][256] floats, in place or not
  *   compceps_frames_kernel   DoCompCeps (etsi/cpp/CompCeps.c:309-318 -> WI8CompCeps :368-549) on
  *                            caller-supplied frames of 201 floats (Data[-1..199])
@@ -86,120 +86,11 @@ __global__ __launch_bounds__(64, SEA_RFFT_WAVES) void rfft256_kernel(const float
     }
 }
 
-namespace {
-
-struct __attribute__((aligned(16))) CcLds {
-    float work[256];
-    float sq[200];
-    float pw[132];   /* 129 power bins */
-    float fb[24];    /* 23 log mel energies */
-};
-
-struct CcConst {
-    FftRegs fft;
-    float win[4];
-    int melStart, melLen;
-    float melW[SEA_CC_TAPS];
-    float dct[SEA_CC_NCHAN];
-    float floorFB, floorE;
-};
-
-__device__ __forceinline__ void load_cc_const(CcConst &C, const sea_cc_tables *t, int lane)
-{
-    load_fft_regs(C.fft, &t->fft, lane);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) C.win[k] = t->win[k][lane];
-    C.melStart = t->melStart[lane];
-    C.melLen = t->melLen[lane];
-#pragma unroll
-    for (int i = 0; i < SEA_CC_TAPS; ++i) C.melW[i] = t->melW[i][lane];
-#pragma unroll
-    for (int j = 0; j < SEA_CC_NCHAN; ++j) C.dct[j] = t->dct[j][lane];
-    C.floorFB = t->floorFB;
-    C.floorE = t->floorE;
-}
-
-/* cur points at Data[0]; Data[-1] is passed separately (prev) so the caller can substitute the
- * zero that precedes the very first denoised sample.  Writes 14 floats. */
-__device__ __forceinline__ void compceps_frame(const float *cur, float prev, float *coef, CcLds &L,
-                                               const CcConst &C, int lane)
-{
-    /* gather Data[i] and Data[i-1] for i = lane + 64k */
-    float d[4], dm1[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = lane + 64 * k;
-        const bool in = i < SEA_WIN;
-        d[k] = in ? cur[i] : 0.0f;
-        dm1[k] = in ? ((i == 0) ? prev : cur[i - 1]) : 0.0f;
-    }
-    /* logE terms (CompCeps.c:413-423): sum of squares in sample order */
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = lane + 64 * k;
-        if (i < SEA_WIN) L.sq[i] = d[k] * d[k];
-    }
-    /* pre-emphasis in double (:427-429), symmetric Hamming (:115-125), zero padding (:439-440) */
-    float e[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = lane + 64 * k;
-        const float pre = (float)((double)d[k] - 0.90 * (double)dm1[k]);
-        e[k] = (i < SEA_WIN) ? pre * C.win[k] : 0.0f;
-    }
-    rfft256(e[0], e[1], e[2], e[3], L.work, C.fft, lane);
-
-    float logE = serial_sum<200>(L.sq, 0.0f);
-    logE = (logE < C.floorE) ? (float)-50.0 : (float)log((double)logE);
-
-    /* power spectrum, products and sum in double (:451-459) */
-    {
-        const int i0 = lane, i1 = lane + 64;
-        const double r0 = (double)L.work[i0], r1 = (double)L.work[i1];
-        const double m0 = (lane > 0) ? (double)L.work[256 - i0] : 0.0, m1 = (double)L.work[256 - i1];
-        L.pw[i0] = (lane > 0) ? (float)(r0 * r0 + m0 * m0) : (float)(r0 * r0);
-        L.pw[i1] = (float)(r1 * r1 + m1 * m1);
-        if (lane == 0) {
-            const double ny = (double)L.work[128];
-            L.pw[128] = (float)(ny * ny);
-        }
-    }
-    wave_sync();
-    /* 23 mel triangles (DoMelFB, MelProc.c:82-104), natural log with floor (:509-513) */
-    if (lane < SEA_CC_NCHAN) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int i = 0; i < SEA_CC_TAPS; ++i) {
-            const int idx = C.melStart + i;
-            const float t = acc + L.pw[idx < 129 ? idx : 128] * C.melW[i];
-            acc = (i < C.melLen) ? t : acc;
-        }
-        L.fb[lane] = (acc < C.floorFB) ? (float)-10.0 : (float)log((double)acc);
-    }
-    wave_sync();
-    /* DCT (:203-227): lanes 0..11 -> c1..c12, lane 12 -> c0, lane 13 -> logE */
-    if (lane < 14) {
-        float acc = 0.0f;
-        if (lane < 12) {
-#pragma unroll
-            for (int j = 0; j < SEA_CC_NCHAN; ++j) acc += L.fb[j] * C.dct[j];
-        } else if (lane == 12) {
-#pragma unroll
-            for (int j = 0; j < SEA_CC_NCHAN; ++j) acc += L.fb[j];
-        } else
-            acc = logE;
-        coef[lane] = acc;
-    }
-    wave_sync();
-}
-
-} // namespace
-
 /* ==================================================================================================
  * Tiled CompCeps: one wave owns a TILE of kCcT consecutive frames.
  *
- * The one-frame-per-wave form above spends most of its time on work that every one of its 64 lanes
- * repeats: the frame's 200-term in-order energy sum (CompCeps.c:413-423) and its double-precision log.
+ * A one-frame-per-wave form (round 1: 2.5 ms for 810 511 frames) spends most of its time on work that every one of
+ * its 64 lanes repeats: the frame's 200-term in-order energy sum (CompCeps.c:413-423) and its double-precision log.
  * Here the tile's samples are staged in LDS once and
  *   * the energy sums run LANE = FRAME (lane f adds the 200 squares of frame f in order; the hop
  *     blocks sit 81 words apart -- one pad word per 80 samples -- so the 16 lanes hit 16 banks),
@@ -209,8 +100,8 @@ __device__ __forceinline__ void compceps_frame(const float *cur, float prev, flo
  *     (frame, band));
  *   * the 23 log energies of all frames are taken lane = (frame, band) flattened (6 evaluations of the
  *     double log per tile instead of 16), the DCT lane = (frame, coefficient) flattened (4 passes).
- * Arithmetic per value is compceps_frame()'s, operation by operation; only the distribution over
- * lanes changes.  Zero-weight taps stand in for the band length test (acc + p * 0 == acc: p is a
+ * Arithmetic per value is WI8CompCeps' (CompCeps.c:368-549), operation by operation: pre-emphasis in double
+ * (:427-429), power spectrum products and sum in double (:451-459), taps / DCT terms in their order.  Zero-weight taps stand in for the band length test (acc + p * 0 == acc: p is a
  * finite power, acc >= +0) and c0's plain sum is a DCT row of ones (x * 1.0f == x).
  * ================================================================================================ */
 namespace {
@@ -443,8 +334,7 @@ __global__ __launch_bounds__(64) void compceps_kernel(CepsArgs a)
  * ================================================================================================ */
 namespace {
 
-struct __attribute__((aligned(16))) WpLds {
-    float frame[204]; /* frame[0] = Data[-1], frame[1..200] = Data[0..199] */
+struct __attribute__((aligned(16))) WpLds { /* scratch of DoWaveProc for one frame */
     float tw[200];
     int q[200], sm[200];
     int pos[24];
@@ -477,25 +367,13 @@ __device__ __forceinline__ int wave_argmax(int value, int index, bool valid, boo
     return lowWins ? 255 - c : c;
 }
 
-/* DoWaveProc (WaveProc.c:397-455) on W.frame[1..200], in place: Teager energy (:216-226), its 9-point
- * integer smoothing, maxima 25..79 samples apart (:102-190), a two-level window around them
- * (:244-330).  Ends with wave_sync(). */
-__device__ __forceinline__ void waveproc_frame(WpLds &W, float *sq, int lane)
+/* DoWaveProc (WaveProc.c:397-455) on d[0..199], in place, for a frame whose low-energy check (:423-427: in-order
+ * sum of squares >= 100, evaluated by the caller lane = frame) has passed: Teager energy (:216-226), its 9-point
+ * integer smoothing, maxima 25..79 samples apart (:102-190), a two-level window around them (:244-330).
+ * Ends with wave_sync(). */
+__device__ __forceinline__ void waveproc_frame(WpLds &W, float *d, int lane)
 {
     constexpr int N = 200;
-    float *d = W.frame + 1;
-    /* low-energy check: in-order sum of squares (:423-427) */
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = lane + 64 * k;
-        if (i < N) sq[i] = d[i] * d[i];
-    }
-    wave_sync();
-    const float energy = serial_sum<200>(sq, 0.0f);
-    if (!((double)energy >= 100.0)) { /* wave-uniform */
-        wave_sync();
-        return;
-    }
     /* Teager energy and its integer quarter, (int)floor(T * 0.25 + 0.5) in double */
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -614,42 +492,62 @@ __device__ __forceinline__ void waveproc_frame(WpLds &W, float *sq, int lane)
 
 } // namespace
 
+/* WaveProc + CompCeps of the restored feature chain, tiled like compceps_kernel: a wave owns 16 consecutive
+ * cepstral frames of one utterance as SEPARATE 201-float frames in LDS (WaveProc reshapes each frame in place, so
+ * they cannot share samples).  The low-energy check's in-order sum of squares runs lane = frame; the frames that
+ * pass go through DoWaveProc one after the other (wave-wide peak search), then the tile through cc_tile(). */
 __global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
 {
-    __shared__ CcLds L;
+    __shared__ CcTileLds<false> L;
     __shared__ WpLds W;
     const int lane = threadIdx.x;
-    CcConst C;
-    load_cc_const(C, a.tables, lane);
-    const long long total = a.ceps_cum[a.n_utt];
-    for (long long g = blockIdx.x; g < total; g += gridDim.x) {
-        int lo = 0, hi = a.n_utt; /* largest u with ceps_cum[u] <= g */
+    CcTileConst C;
+    load_cc_tile_const<false>(C, L, a.tables, lane);
+    const long long nslot = a.ceps_cum[a.n_utt] / kCcT + a.n_utt; /* tile slots as in compceps_kernel */
+    for (long long s = blockIdx.x; s < nslot; s += gridDim.x) {
+        int lo = 0, hi = a.n_utt;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (a.ceps_cum[mid] <= g) lo = mid; else hi = mid;
+            if (a.ceps_cum[mid] / kCcT + mid <= s) lo = mid; else hi = mid;
         }
         const int u = lo;
-        const long long j = g - a.ceps_cum[u];
+        const long long c0 = a.ceps_cum[u], cap = a.ceps_cum[u + 1] - c0;
+        const long long j0 = (s - (c0 / kCcT + u)) * kCcT;
+        if (j0 >= cap) continue;
         const int f0 = a.first_out[u];
         const long long nfr = a.lengths[u] / SEA_HOP;
         const long long nout = (f0 >= 0) ? nfr - f0 : 0;
         const long long nceps = (nout >= 3) ? nout - 2 : 0;
-        if (j == 0 && lane == 0 && a.n_ceps) a.n_ceps[u] = (int)nceps;
-        float *dst = a.feat_cc + g * SEA_CC_NCEP;
-        if (j < nceps) {
-            /* frameBuf of ParmInterface.c:281: Data[-1..199] = the last 241 denoised samples minus 40 */
-            const float *cur = a.den_f32 + a.offsets[u] + (f0 + j) * SEA_HOP;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = lane + 64 * k; /* frame[i] = Data[i-1] */
-                if (i <= SEA_WIN) W.frame[i] = (i == 0) ? ((j == 0) ? 0.0f : cur[-1]) : cur[i - 1];
+        if (j0 == 0 && lane == 0 && a.n_ceps) a.n_ceps[u] = (int)nceps;
+        const int nrow = (int)((cap - j0 < kCcT) ? cap - j0 : kCcT);
+        long long left = nceps - j0;
+        const int nv = (int)(left < 0 ? 0 : (left > nrow ? nrow : left));
+        float *dst = a.feat_cc + (c0 + j0) * SEA_CC_NCEP;
+        if (nv > 0) {
+            /* frameBuf of ParmInterface.c:281 for cepstral frame j: Data[-1..199] = the float NoiseSup stream from
+             * sample 80 (f0 + j) - 1 on; Data[-1] of the utterance's first cepstral frame is 0 */
+            const float *cur0 = a.den_f32 + a.offsets[u] + (f0 + j0) * SEA_HOP;
+            for (int i = lane; i < nv * 201; i += kLanes) {
+                const int f = i / 201, x = i - f * 201;
+                L.span[i] = (x == 0 && f == 0 && j0 == 0) ? 0.0f : cur0[SEA_HOP * f + x - 1];
             }
             wave_sync();
-            waveproc_frame(W, L.sq, lane);
-            compceps_frame(W.frame + 1, W.frame[0], dst, L, C, lane);
-        } else if (lane < SEA_CC_NCEP) {
-            dst[lane] = 0.0f;
+            float energy = 0.0f; /* WaveProc.c:423-427, lane = frame */
+            if (lane < nv) {
+                const float *p = L.span + 201 * lane;
+#pragma unroll 8
+                for (int x = 1; x < 201; ++x) {
+                    const float v = p[x];
+                    energy += v * v;
+                }
+            }
+            const unsigned long long pass = __ballot(lane < nv && (double)energy >= 100.0);
+            for (int f = 0; f < nv; ++f)
+                if ((pass >> f) & 1ull) waveproc_frame(W, L.span + 201 * f + 1, lane);
+            wave_sync();
+            cc_tile<false>(L, C, nv, dst, lane);
         }
+        for (int idx = nv * SEA_CC_NCEP + lane; idx < nrow * SEA_CC_NCEP; idx += kLanes) dst[idx] = 0.0f;
     }
 }
 
