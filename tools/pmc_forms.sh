@@ -1,6 +1,6 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-for form in pipe pipe6 big; do
+for form in ${FORMS:-pipe pre}; do
   export SEA_NS_KERNEL=$form
   rm -rf /tmp/pf_$form
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES \

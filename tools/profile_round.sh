@@ -1,24 +1,33 @@
 #!/bin/bash
-# tools/profile_round.sh [tag] -- everything the profiles/ directory is made of, in one GPU-box call:
-# bench line, extra-kernel bench lines, kernel-trace stats of both, HBM FETCH/WRITE passes (separate
-# --pmc runs, no trace domains mixed in).  Summaries land in gpurun_out/<tag>_*; copy them to profiles/.
-set -e
-TAG=${1:-r01}
+# tools/profile_round.sh [tag] -- everything the profiles/ directory is made of, in one GPU-box call: the bench line
+# (with its also-array), kernel-trace stats of the same command, HBM FETCH / WRITE counter passes (separate --pmc
+# runs, no trace domains mixed in) -> profiles/pmc_traffic.json stamped with the kernel-source sha, SQ counter
+# passes of the NoiseSup kernel.  Summaries land in gpurun_out/<tag>_*; copy them to profiles/.
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-python bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err
-python tools/bench_extra.py --steps 5 > $O/${TAG}_bench_extra_1024.jsonl 2> /dev/null
+python bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err || { tail -5 $O/${TAG}_bench_n1.err; exit 1; }
+python tools/bench_extra.py --what subband,afe,host --steps 5 > $O/${TAG}_bench_extra_1024.jsonl 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ns -- python3 $R/bench.py --steps 10 --no-cpu-baseline > /tmp/p_ns.log 2>&1
-python3 $R/tools/prof_summary.py /tmp/p_ns $O/${TAG}_ns_kernel_trace_stats.txt --delete-raw > /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ex -- python3 $R/tools/bench_extra.py --what resynth,ibm,subband,ceps,rfft --steps 4 > /tmp/p_ex.log 2>&1
-python3 $R/tools/prof_summary.py /tmp/p_ex $O/${TAG}_extra_kernels_trace_stats.txt --delete-raw > /dev/null
+rm -rf /tmp/p_tr
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_tr -- python3 $R/bench.py --steps 10 --no-cpu-baseline > /tmp/p_tr.log 2>&1
+python3 $R/tools/prof_summary.py /tmp/p_tr $O/${TAG}_kernel_trace_stats.txt --delete-raw > /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -- python3 $R/tools/bench_extra.py --what resynth,subband --steps 2 > /tmp/p_$c.log 2>&1
-  python3 $R/tools/prof_summary.py /tmp/p_$c $O/${TAG}_resynth_pmc_$(echo $c | tr A-Z a-z | sed s/_size//).txt --delete-raw > /dev/null
-  rocprofv3 --pmc $c --output-format csv -d /tmp/q_$c -- python3 $R/bench.py --steps 4 --no-cpu-baseline > /tmp/q_$c.log 2>&1
-  python3 $R/tools/prof_summary.py /tmp/q_$c $O/${TAG}_ns_pmc_$(echo $c | tr A-Z a-z | sed s/_size//).txt --delete-raw > /dev/null
+  rm -rf /tmp/p_$c
+  rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -- python3 $R/bench.py --steps 3 --warmup 1 --also-steps 2 --no-cpu-baseline > /tmp/p_$c.log 2>&1
+  python3 $R/tools/prof_summary.py /tmp/p_$c $O/${TAG}_pmc_$(echo $c | tr A-Z a-z | sed s/_size//).txt --delete-raw > /dev/null
 done
+python3 $R/tools/make_pmc_traffic.py $O/${TAG}_pmc_fetch.txt $O/${TAG}_pmc_write.txt $O/pmc_traffic.json
+i=0
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" \
+           "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_SCA"; do
+  i=$((i+1))
+  rm -rf /tmp/p_sq$i
+  rocprofv3 --pmc $set --output-format csv -d /tmp/p_sq$i -- python3 $R/bench.py --steps 3 --warmup 1 --also-steps 2 --no-cpu-baseline > /tmp/p_sq$i.log 2>&1
+  python3 $R/tools/prof_summary.py /tmp/p_sq$i $O/${TAG}_pmc_sq$i.txt --delete-raw > /dev/null
+done
+cd $R
+python bench.py --no-cpu-baseline > $O/${TAG}_bench_n1_with_traffic.json 2> /dev/null   # same tree, traffic from the fresh stamp
 echo profile_round done
