@@ -18,9 +18,10 @@ sys.path.insert(0, ROOT)
 def parse(path, counter):
     out = {}
     for line in open(path):
-        m = re.match(r"sea::(\w+)\(.*\) " + counter + r": dispatches=(\d+) mean=([\d.]+)", line)
+        m = re.match(r"sea::(\w+)\(.*\) " + counter + r": dispatches=(\d+) mean=([\d.]+) min=([\d.]+)", line)
         if m:
-            out[m.group(1)] = float(m.group(3))
+            out[m.group(1)] = float(m.group(4))  # min over the dispatches: the plain launches (one NoiseSup launch of the
+            #                                      run also writes the float stream for CompCeps: +256 B per frame)
     return out
 
 
@@ -31,8 +32,8 @@ def main():
             "compceps_kernel": "compceps_bytes_per_launch", "rfft256_kernel": "rfft256_bytes_per_launch"}
     j = {"_comment": "HBM traffic per launch on the bench.py workloads (configs[1] corpus, 1024 utterances; rfft256: 2^18 frames), "
                      "from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes = 2 * FETCH_KiB * 1024 + WRITE_KiB * 1024 "
-                     "(gfx950 FETCH_SIZE correction, see tools/make_pmc_traffic.py).  resynth: the mean over the ratio-mask and the "
-                     "binary-mask launches (same traffic).",
+                     "(gfx950 FETCH_SIZE correction, see tools/make_pmc_traffic.py); per kernel the minimum over its dispatches "
+                     "(the bench's plain launches).",
          "source_stamp": bench.source_stamp(), "fetch_kib": fetch, "write_kib": write}
     for k, name in keys.items():
         if k in fetch and k in write:

@@ -19,7 +19,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -- python3 $R/bench.py --steps 3 --warmup 1 --also-steps 2 --no-cpu-baseline > /tmp/p_$c.log 2>&1
   python3 $R/tools/prof_summary.py /tmp/p_$c $O/${TAG}_pmc_$(echo $c | tr A-Z a-z | sed s/_size//).txt --delete-raw > /dev/null
 done
-python3 $R/tools/make_pmc_traffic.py $O/${TAG}_pmc_fetch.txt $O/${TAG}_pmc_write.txt $O/pmc_traffic.json
+python3 $R/tools/make_pmc_traffic.py $O/${TAG}_pmc_fetch.txt $O/${TAG}_pmc_write.txt $O/pmc_traffic.json && cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_SCA"; do
