@@ -223,8 +223,12 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
          * (valid, tick) of frames i, i-1, i-2 stay in registers: B0 only copies them from Rec01 to Rec12. */
         int vCur = 0, tCur = 0, v1 = 0, t1 = 0, v2 = 0, t2 = 0;
         auto intake = [&](long long f) {
+            /* the 80-VGPR form has no register left for the lane id across the transform: the allocator would park it
+             * (and 8 * lane) in scratch and reload both every frame; two v_mbcnt recompute it instead */
+            int ln = lane;
+            if (ADDR_LDS) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
             const uint32_t w = nextw;
-            if (f + 1 < nfr && lane < 40) nextw = in32[(f + 1) * 40 + lane];
+            if (f + 1 < nfr && ln < 40) nextw = in32[(f + 1) * 40 + ln];
             const bool any = __ballot(w != 0u) != 0ull;
             vCur = 0;
             if (any || tick > 0) {
@@ -232,7 +236,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                 if (FD && tick == 0) onset = (int)f;
                 tick++;
                 const float x0 = (float)(short)(w & 0xFFFFu), x1 = (float)(short)(w >> 16);
-                if (lane < 40) slot_store(L.circ[0], tick, lane, x0, x1);
+                if (ln < 40) slot_store(L.circ[0], tick, ln, x0, x1);
             }
             tCur = tick;
         };
@@ -439,14 +443,16 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                 NS_T_CK(3);
             }
             if (haveOut) {
-                if (lane < 40) {
+                int ln = lane; /* 80-VGPR form: recomputed, or the per-lane store address lives in scratch (see F's intake) */
+                if (ADDR_LDS) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+                if (ln < 40) {
                     uint32_t packed = 0u;
                     if (produced) {
-                        const float2 v = *reinterpret_cast<const float2 *>(&L.sout[2 * lane]);
+                        const float2 v = *reinterpret_cast<const float2 *>(&L.sout[2 * ln]);
                         packed = (uint32_t)cast_i16(v.x) | ((uint32_t)cast_i16(v.y) << 16);
-                        if (outf) *reinterpret_cast<float2 *>(outf + fo * SEA_HOP + 2 * lane) = v;
+                        if (outf) *reinterpret_cast<float2 *>(outf + fo * SEA_HOP + 2 * ln) = v;
                     }
-                    out32[fo * 40 + lane] = packed;
+                    out32[fo * 40 + ln] = packed;
                 }
                 if (FD && produced && lane == 0 && a.flags_out)
                     a.flags_out[off / 8 + 10 * fo] = (unsigned char)L.fdFlags[L.r34[fo & 1].tick & (kSlots - 1)];
@@ -468,7 +474,10 @@ __global__ __launch_bounds__(256, SEA_NS_MIN_WAVES) void ns_denoise_pipe_kernel(
 /* the same arithmetic with the transform's address tables in LDS instead of VGPRs: 80 instead of 110
  * VGPRs, six workgroups per CU instead of four -- the form to launch when the batch has more than four
  * utterances per CU (373 vs 331 M frames/s at 4096 utterances; 267 vs 298 M at 1024) */
-__global__ __launch_bounds__(256, 6) void ns_denoise_pipe_big_kernel(NsBatchArgs a) { ns_pipe_body<false, true>(a); }
+#ifndef SEA_NS_BIG_WAVES
+#define SEA_NS_BIG_WAVES 6
+#endif
+__global__ __launch_bounds__(256, SEA_NS_BIG_WAVES) void ns_denoise_pipe_big_kernel(NsBatchArgs a) { ns_pipe_body<false, true>(a); }
 
 /* the same pipeline with the first stage's speech measures (SpeechQVar/Spec/Mel, VADNS) evaluated in
  * B0 and their four bits stored per output frame: input of the frame-dropping VAD */
