@@ -246,6 +246,38 @@ def test_resynth_known_answer(oracle):
     assert list(got[8000:8010]) == [88, 528, 249, 1331, 1271, 1638, 2190, 1682, 1642, 2182]
 
 
+def test_resynth_utterances_chunked_by_scratch_budget(oracle, monkeypatch):
+    """sea_resynth_utterances (the host-buffer entry the file driver uses) cuts the list into sub-batches whose
+    256-B-per-sample HBM intermediate fits a budget (60 % of the free HBM; SEA_RESYNTH_SCRATCH_MB overrides it) and
+    reuses ONE scratch allocation for all of them.  A 3 MB budget forces seven utterances of 1.2-4.1 MB each into
+    several sub-batches, the largest alone; every utterance must equal the oracle whatever the cut."""
+    import ctypes
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    _torch()
+    lib = sea.load()
+    lens = [4800, 16000, 8000, 4800, 12000, 6400, 16000]
+    utts = [corpus.synth_utterance(200 + i, L) for i, L in enumerate(lens)]
+    masks = [corpus.synth_mask(200 + i, L) for i, L in enumerate(lens)]
+    want = [oracle.resynth64(x, m) for x, m in zip(utts, masks)]
+
+    def run():
+        outs = [np.zeros_like(x) for x in utts]
+        n = len(utts)
+        pin = (ctypes.c_void_p * n)(*[x.ctypes.data for x in utts])
+        pm = (ctypes.c_void_p * n)(*[m.ctypes.data for m in masks])
+        po = (ctypes.c_void_p * n)(*[y.ctypes.data for y in outs])
+        pl = (ctypes.c_long * n)(*lens)
+        assert lib.sea_resynth_utterances(pin, pl, pm, 0, po, n) == 0, lib.sea_last_error()
+        return outs
+    monkeypatch.setenv("SEA_RESYNTH_SCRATCH_MB", "3")
+    for got, w in zip(run(), want):
+        assert np.array_equal(got, w)
+    monkeypatch.delenv("SEA_RESYNTH_SCRATCH_MB")
+    for got, w in zip(run(), want):
+        assert np.array_equal(got, w)
+
+
 def test_gammatone_filter_vs_oracle(oracle):
     import speech_enhancement_amd as sea
     _torch()
