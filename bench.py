@@ -369,6 +369,53 @@ def also_lines(batch, ids, device, steps):
          n, "frames/s", n * CC_BYTES_PER_FRAME, ker, wall, "sea::compceps_kernel", "compceps_bytes_per_launch")
     del f32, res
 
+    # subbband() (gammatone + hair cell -> 64 int16 streams) and the IRM target computed from
+    # two such blocks (here the same block twice: the timing does not depend on the values)
+    sub = torch.zeros(batch.total * 64, dtype=torch.int16, device=device)
+    ker, wall = timed_steps(lambda: sea.subband_batch(batch, out=sub), max(2, steps // 2), 1)
+    samples = int(np.sum(batch.host_lengths))
+    line("subbband", f"SURVEY 8(f) #1: {batch.n_utt} utterances, 64-channel gammatone + Meddis hair cell to 64 int16 streams "
+                     "(2 B read + 128 B written per sample)", samples, "samples/s", samples * 130, ker, wall,
+         "sea::subband_kernel", "subband_bytes_per_launch")
+    ker, wall = timed_steps(lambda: sea.irm_target_batch(batch, sub, sub), max(2, steps // 2), 1)
+    line("IRM target", f"SURVEY 8(f) #2: make_single_IBM's ratio-mask target from two subband blocks, {hops} frames x 64 channels "
+                       "(2 x 128 B x 160 samples read + 256 B written per frame)", hops, "hop-frames/s",
+         hops * (2 * 128 * 160 + 256), ker, wall, "sea::irm_target_kernel", "irm_bytes_per_launch")
+    del sub
+
+    # the restored feature chain (NoiseSup with speech flags -> WaveProc -> CompCeps -> PostProc -> VAD),
+    # three launches on device-resident buffers (the C ABI directly: engine.afe_features_batch also unpacks on the host)
+    lib = sea.load()
+    n = batch.n_utt
+    outb = torch.zeros_like(batch.data)
+    f32 = torch.zeros(batch.total, dtype=torch.float32, device=device)
+    first = torch.full((n,), -1, dtype=torch.int32, device=device)
+    onset = torch.zeros(n, dtype=torch.int32, device=device)
+    flags = torch.zeros(batch.total // 8, dtype=torch.uint8, device=device)
+    nfr = np.asarray(batch.host_lengths) // 80
+    ccum = np.concatenate(([0], np.cumsum(np.maximum(nfr - 6, 0)))).astype(np.int64)
+    fcum = np.concatenate(([0], np.cumsum(nfr + 6))).astype(np.int64)
+    tc, tf = int(ccum[-1]), int(fcum[-1])
+    fcc = torch.zeros((tc, 14), dtype=torch.float32, device=device)
+    f15 = torch.zeros((tf, 15), dtype=torch.float32, device=device)
+    nfe = torch.zeros(n, dtype=torch.int32, device=device)
+    d_ccum, d_fcum = torch.from_numpy(ccum).to(device), torch.from_numpy(fcum).to(device)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run_afe():
+        P = lambda t: t.data_ptr()
+        assert lib.sea_ns_denoise_batch_fd(P(batch.data), P(outb), P(f32), P(batch.offsets), P(batch.lengths), P(batch.order),
+                                           P(first), P(flags), P(onset), n, st) == 0
+        assert lib.sea_afe_features_batch(P(f32), P(flags), P(batch.offsets), P(batch.lengths), P(first), P(onset), P(d_ccum),
+                                          tc, P(fcc), None, P(d_fcum), P(f15), P(nfe), None, n, st) == 0
+    ker, wall = timed_steps(run_afe, max(2, steps // 2), 1)
+    emitted = int(nfe.sum().item())
+    line("AFE feature chain", f"SURVEY 8(f) #3: {n} utterances, {emitted} emitted feature frames of 15 floats, three launches "
+                              "(NoiseSup with speech flags | WaveProc + CompCeps | PostProc + VAD + flush)", emitted,
+         "feature frames/s", batch.n_frames * 320 + emitted * 60, ker, wall,
+         "sea::ns_denoise_pipe_fd_kernel + sea::afe_ceps_kernel + sea::afe_vad_kernel", "afe_bytes_per_launch")
+    del outb, f32, flags, fcc, f15
+
     # rfft256 on a streaming batch
     nfr = 1 << 18
     x = torch.randn(nfr, 256, device=device)
