@@ -36,6 +36,7 @@ import contextlib
 import hashlib
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys
@@ -264,6 +265,7 @@ def cpu_baseline(batch, n_sample, threads):
                                os.path.join(ROOT, "oracle", "ns_oracle.c"), os.path.join(ROOT, "oracle", "resynth_oracle.c"),
                                "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         speed = O.Oracle(path=so)
+        shutil.rmtree(tmp, ignore_errors=True)  # the mapping stays valid after the file is gone
         dt_spd, _ = _time_cpu(speed.etsi_denoise, utts, cores, passes)
         res["speed_build_value"] = passes * frames / dt_spd
         res["speed_build"] = "gcc -O3 -march=native (FMA allowed: not bit-exact, timing only)"
