@@ -55,7 +55,9 @@ void rfft(float *x, int n, int m);
 /* ----------------------------------------------------------------------------------------------
  * library state
  * -------------------------------------------------------------------------------------------- */
-int sea_init(int device);            /* device < 0: keep the current HIP device */
+int sea_init(int device);            /* device < 0: keep the current HIP device; >= 0: make it the calling thread's device */
+int sea_device_count(void);          /* usable HIP devices (0 when there is none); one host thread per device is the
+                                      * multi-GPU model: utterances are independent, nothing crosses between devices */
 const char *sea_last_error(void);
 const char *sea_version(void);
 /* Device-resident constant tables, for callers that want to inspect them (tests). */

@@ -22,6 +22,7 @@ PROTOTYPES = {
     "etsi_denoise_16k_synchronization": (_i, [_vp, _vp, _l]),
     "rfft": (None, [_vp, _i, _i]),
     "sea_init": (_i, [_i]),
+    "sea_device_count": (_i, []),
     "sea_last_error": (_c.c_char_p, []),
     "sea_version": (_c.c_char_p, []),
     "sea_tables_host": (_i, [_vp] * 11),

@@ -201,6 +201,13 @@ extern "C" {
 const char *sea_last_error(void) { return g_err; }
 const char *sea_version(void) { return "sea_mi355x 0.1 (gfx950)"; }
 
+int sea_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
 int sea_init(int device)
 {
     if (device >= 0) HIP_TRY(hipSetDevice(device));

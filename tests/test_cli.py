@@ -84,6 +84,25 @@ def test_cli_fails_loudly_without_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_etsi_denoise_thread_pool(tmp_path, oracle):
+    """The file driver's multi-device shape -- host threads pulling chunks of the list from a shared counter, one
+    thread per device (the reference's pool: aurora_speech_enhancement.cpp:111-121, 311-327).  On a one-GPU box
+    SEA_DEVICES=3 makes three threads share the card: 200 utterances in chunks of 64, every output WAV equals the
+    oracle whatever thread and chunk produced it."""
+    from speech_enhancement_amd import corpus
+    _need_bins()
+    utts = [corpus.synth_utterance(300 + k, 800 + 80 * (k % 7) + (k % 3)) for k in range(200)]
+    out, ids = _workspace(tmp_path, utts, with_nummix=True)
+    r = subprocess.run([os.path.join(BIN, "etsi_denoise"), out + "cfg.txt"], capture_output=True, text=True,
+                       env=dict(os.environ, SEA_DEVICES="3"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    for i, x in zip(ids, utts):
+        y, fs = _read_wav(out + f"resynth_e/{i}_e_resynth.wav")
+        want = oracle.etsi_denoise(x, fill=0)
+        assert fs == 16000 and np.array_equal(y, want), i
+
+
+@pytest.mark.gpu
 def test_cli_etsi_denoise_end_to_end(tmp_path, oracle):
     from speech_enhancement_amd import corpus
     _need_bins()
