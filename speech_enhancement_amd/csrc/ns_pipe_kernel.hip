@@ -57,6 +57,7 @@ constexpr int kPipeWaves = 4;
  * working / waiting at the frame barrier -> g_ns_timing[role*2 + {0,1}] */
 #ifdef SEA_NS_TIMING
 __device__ unsigned long long g_ns_timing[24]; /* [8..15]: checkpoints inside S */
+__device__ unsigned g_ns_hw[4096 * 4];           /* per workgroup and role: HW_ID of the wave (SIMD placement, tools/ns_placement.py) */
 __device__ unsigned g_ns_wg[4096 * 4];           /* per workgroup: frame-loop span in 10 ns ticks, HW_ID, XCC_ID, start tick (low 32 bits) */
 struct RoleTimer {
     unsigned long long work = 0, wait = 0, t0 = 0, t1 = 0;
@@ -204,6 +205,10 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
     block_sync();
 
     NS_T_DECL;
+#ifdef SEA_NS_TIMING
+    if (blockIdx.x < 4096 && lane == 0)
+        g_ns_hw[blockIdx.x * 4 + role] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) | ((__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20) & 0xFu) << 28);
+#endif
     if (role == 0) {
         /* ---- F: input + zero-frame gate (ParmInterface.c:244-251); front halves of both stages ---- */
         Fft2Regs fft;
@@ -497,6 +502,10 @@ extern "C" int sea_debug_ns_back_ck(unsigned long long *out16, int reset)
 extern "C" int sea_debug_ns_wg(unsigned *out, int n_wg)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sea::g_ns_wg), (size_t)n_wg * 4 * sizeof(unsigned));
+}
+extern "C" int sea_debug_ns_hw(unsigned *out, int n_wg)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sea::g_ns_hw), (size_t)n_wg * 4 * sizeof(unsigned));
 }
 extern "C" int sea_debug_ns_timing(unsigned long long *out8)
 {

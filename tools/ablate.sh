@@ -7,6 +7,6 @@ for i in $(seq $R); do
   for so in "" ablate/*.so; do
     [ "$so" = "ablate/*.so" ] && continue
     if [ -n "$so" ]; then export SEA_MI355X_LIB=$PWD/$so; else unset SEA_MI355X_LIB; fi
-    python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('${so:-baseline}', round(d['ms_per_step'],3), 'ms')"
+    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-also 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('${so:-baseline}', round(d['ms_per_step'],3), 'ms')"
   done
 done
