@@ -7,8 +7,10 @@ Stated tolerances:
   * rfft: bit-exact (same butterflies, same order, no FMA).
   * float NoiseSup stream / Wiener internals: |delta| <= 1e-4 * max(1, |ref|).
   * CompCeps: |delta| <= 1e-3 absolute per coefficient.
-The kernels are written to be bit-identical except for double-precision log/log10 (device libm vs
-glibc, < 1 ulp each before rounding to float); the tests print how exact the match actually was.
+The kernels are written to be bit-identical: the two double-precision logarithms per frame are guarded
+(a result within the error bound of a float rounding boundary is recomputed in double-double arithmetic,
+ns_core.h; swept over every float argument by test_selftest_log_guard_sweep), so the stated tolerances are
+the contract and the known-answer / full-size tests assert equality; the tests print how exact the match was.
 """
 import numpy as np
 import pytest
