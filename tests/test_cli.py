@@ -71,6 +71,69 @@ def test_cli_dry_run_parses_cfg_list_and_wavs(tmp_path):
     assert r.returncode != 0 and "cannot read" in r.stderr
 
 
+def test_cli_host_layer_under_sanitizers(tmp_path):
+    """The host C layer (cfg / list / WAV / mask-text parsing, chunking) built with AddressSanitizer + UBSan on the
+    CPU (the GPU pool offers no sanitizer runs): dry runs over a good workspace, a truncated WAV, a missing file and a
+    ragged mask must end without a sanitizer report."""
+    from speech_enhancement_amd import corpus
+    host = os.path.join(ROOT, "speech_enhancement_amd", "host")
+    libdir = os.path.join(ROOT, "speech_enhancement_amd")
+    san = str(tmp_path / "san")
+    os.makedirs(san)
+    flags = ["-O1", "-g", "-Wall", "-std=gnu99", "-pthread", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+    link = ["-L" + libdir, "-lsea_mi355x", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib", "-lamdhip64", "-lstdc++", "-lm"]
+    bins = {}
+    for name, src, extra in (("etsi_denoise", "etsi_denoise_main.c", []), ("resynth", "enhance_resyth_subband_main.c", []),
+                             ("resynth_ibm", "enhance_resyth_subband_main.c", ["-DSEA_IBM=1"])):
+        bins[name] = os.path.join(san, name)
+        subprocess.check_call(["gcc"] + flags + extra + ["-o", bins[name], os.path.join(host, src), os.path.join(host, "sea_host.c")] + link)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+
+    def run(binary, cfg):
+        r = subprocess.run([binary, cfg, "--dry-run"], capture_output=True, text=True, env=env)
+        assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+        return r
+
+    utts = [corpus.synth_utterance(k, 800 + 90 * k) for k in range(4)]
+    out, ids = _workspace(tmp_path, utts, with_nummix=True)
+    assert run(bins["etsi_denoise"], out + "cfg.txt").returncode == 0
+    os.makedirs(tmp_path / "rs")
+    rout, rids = _workspace(tmp_path / "rs", utts, with_nummix=False)   # the resynthesis cfg has no numMix line
+    assert rids == ids
+    for b in ("resynth", "resynth_ibm"):
+        assert run(bins[b], rout + "cfg.txt").returncode != 0     # no result.txt yet: reported, not crashed
+    # mask text (show_IBM.cpp:194-208 format): a full matrix, one with short rows and too few rows, one with too many
+    # rows and an over-long line, and more matrices than the list has ids
+    rng = np.random.default_rng(5)
+    with open(rout + "result.txt", "w") as f:
+        for k, x in enumerate(utts + [utts[0]]):
+            rows = (len(x) - 320) // 160 + 1
+            f.write(f"{ids[k % len(ids)]}  [\n")
+            nrows = rows if k == 0 else (max(rows - 2, 0) if k == 1 else rows + 3)
+            for r in range(nrows):
+                ncol = 64 if k != 1 else 17
+                vals = " ".join(f"{v:.6f}" for v in rng.random(ncol))
+                if k == 2 and r == 1:
+                    vals = vals + " " + " ".join("0.123456789012345678901234567890" for _ in range(80))
+                f.write("  " + vals + (" ]\n" if r == nrows - 1 else "\n"))
+    for b in ("resynth", "resynth_ibm"):
+        r = run(bins[b], rout + "cfg.txt")
+        assert r.returncode == 0, r.stderr
+        assert all(i in r.stdout for i in ids)
+    # truncated WAV (header promises more data than the file holds) and a header-only file
+    wav = out + f"noisy/{ids[1]}_noisy.wav"
+    data = open(wav, "rb").read()
+    open(wav, "wb").write(data[:44 + 101])
+    open(out + f"noisy/{ids[2]}_noisy.wav", "wb").write(data[:20])
+    os.remove(out + f"noisy/{ids[3]}_noisy.wav")
+    r = run(bins["etsi_denoise"], out + "cfg.txt")
+    assert r.returncode != 0
+    # a cfg that names a list which does not exist, and an empty cfg
+    open(out + "empty.txt", "w").write("")
+    assert run(bins["etsi_denoise"], out + "empty.txt").returncode != 0
+    assert run(bins["etsi_denoise"], out + "nonexistent.txt").returncode != 0
+
+
 def test_cli_fails_loudly_without_gpu(tmp_path):
     import torch
     if torch.cuda.is_available():
