@@ -33,6 +33,7 @@ steps each, timed in the same run.
 """
 import argparse
 import contextlib
+import datetime
 import hashlib
 import json
 import os
@@ -91,10 +92,20 @@ def spawn_ranks(n, argv):
                    MASTER_PORT=str(port), SEA_BENCH_SPAWNED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # a rank that dies would leave the others waiting at the next barrier: when one exits non-zero, end the rest
+    # (exactly the processes started here)
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = max(rc, abs(p.returncode))
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            if p.poll() is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(p.returncode))
+            if p.returncode != 0:
+                for q in live:
+                    q.terminate()
     return rc
 
 
@@ -218,7 +229,8 @@ def init_gloo(rank, world):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     with stdout_to_stderr():
-        dist.init_process_group("gloo", rank=rank, world_size=world)  # host side: barrier + two scalars
+        dist.init_process_group("gloo", rank=rank, world_size=world,   # host side: barrier + two scalars
+                                timeout=datetime.timedelta(seconds=600))
         dist.barrier()
 
 
@@ -441,6 +453,8 @@ def rehearse_cpu(args, world, rank):
     from speech_enhancement_amd.shard import reduce_job
     if world > 1:
         init_gloo(rank, world)
+    if os.environ.get("SEA_BENCH_REHEARSE_FAIL_RANK") == str(rank):   # test hook: a rank that dies after the rendezvous
+        os._exit(7)
     ids = (corpus_shard_ids(args.corpus_utts, args.shards, rank) if args.corpus_utts > 0
            else list(range(rank * args.utts, (rank + 1) * args.utts)))
     frames = int(sum(corpus.utterance_length(int(u)) // 80 for u in ids))

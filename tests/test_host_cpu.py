@@ -204,6 +204,20 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert "\nimport torch" not in head.replace("    import torch", "")
 
 
+def test_bench_launcher_ends_the_job_when_a_rank_dies():
+    """A rank that exits after the rendezvous would leave the others at the next barrier for gloo's timeout: the
+    launcher ends them (the processes it started) and reports the failure at once."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SEA_BENCH_REHEARSE_FAIL_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--utts", "16",
+                        "--rehearse-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert time.time() - t0 < 120
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
 def test_bench_without_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
