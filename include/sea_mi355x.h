@@ -43,10 +43,12 @@ int etsi_denoise(short *p_data, short *p_denoised, long i_frame);
 /* etsi/cpp/AdvFrontEnd.h:14 -- reference behaviour kept: runs etsi_denoise into a scratch buffer
  * and copies only on fault, i.e. never writes p_denoised on success. */
 int etsi_denoise_synchronization(short *p_data, short *p_denoised, long i_frame);
-/* etsi/cpp/AdvFrontEnd.h:16-17 -- the reference's 16 kHz-mode entry points read 80 shorts past a
- * heap buffer per frame and nothing calls them; exported so callers link, they
- * return 1 (fault) without touching p_denoised. */
+/* etsi/cpp/AdvFrontEnd.h:16 -- the reference's 16 kHz-mode entry point reads 80 shorts past a heap
+ * buffer per frame and nothing calls it; exported so callers link, it returns 1 (fault)
+ * without touching p_denoised. */
 int etsi_denoise_16k(short *p_data, short *p_denoised, long i_frame);
+/* etsi/cpp/AdvFrontEnd.h:17 -- AdvFrontEnd.c:316-329 calls the 8 kHz-mode etsi_denoise (not the _16k one): the same
+ * behaviour as etsi_denoise_synchronization, returns 0 and never writes p_denoised on success. */
 int etsi_denoise_16k_synchronization(short *p_data, short *p_denoised, long i_frame);
 /* etsi/cpp/rfft.h:19 -- in-place real split-radix FFT, output Re(0..n/2), Im(n/2-1..1).
  * Only n = 256, m = 8 (the one size on the hot path) is implemented; other sizes abort(). */
@@ -130,15 +132,23 @@ long long sea_resynth_scratch_bytes(long long total_padded_samples, int n_utt);
 /* ----------------------------------------------------------------------------------------------
  * (2) handle-based plug-in equivalents and host-buffer conveniences
  * -------------------------------------------------------------------------------------------- */
-/* Many utterances at once from host memory: packs, uploads, runs one launch, downloads. */
+/* Many utterances at once from host memory -- what etsi/cpp/main.cpp:43-67 does per file and the batch tool
+ * function/20141106_speech_enhancement/aurora_speech_enhancement/aurora_speech_enhancement.cpp:25-80 from a thread
+ * pool.  A copy / compute pipeline (csrc/hostpipe.hip): the list is sorted longest first and cut into chunks of
+ * about SEA_HOST_CHUNK_MB (default 12) MB of int16; a pool of SEA_HOST_THREADS (default min(8, cores - 1)) host
+ * threads packs chunk k+1 into pinned staging and unpacks chunk k-1 while chunk k's H2D copy, launch and D2H copy
+ * run on one of four streams.  out[u][0 .. 80*(lengths[u]/80)) is written, exactly as etsi_denoise does; results
+ * do not depend on the cut. */
 int sea_denoise_utterances(const short *const *in, short *const *out, const long *lengths, int n_utt);
+int sea_host_threads(void); /* size of that pool */
 
 /* DoCompCeps(Data, Coef, This): Data[-1] must be valid (host pointers) */
 int sea_compceps_frame(const float *Data, float *Coef14);
 
 /* resynth(): in/out L samples, mask [F][64] with F=(L-320)/160+1 (host pointers) */
 int sea_resynth64(const short *in, long L, const float *mask, int F, int binary, short *out);
-/* many utterances at once from host memory (masks[u] is [F_u][64]); one pair of launches */
+/* many utterances at once from host memory (masks[u] is [F_u][64]): the same pipeline; a chunk is also bounded by
+ * its share of the HBM scratch budget (60 % of the free HBM over four streams; SEA_RESYNTH_SCRATCH_MB overrides) */
 int sea_resynth_utterances(const short *const *in, const long *lengths, const float *const *masks, int binary,
                            short *const *out, int n_utt);
 /* subbband() (enhancement_extract_test/cpp/extractwav.cpp:40-101): gammatone + Meddis hair cell

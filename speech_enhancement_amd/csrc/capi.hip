@@ -14,12 +14,13 @@
 #include <new>
 #include <vector>
 
-#include "../../include/sea_mi355x.h"
-#include "sea_kernels.h"
+#include "capi_internal.h"
+
+namespace sea_capi {
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
 int fail(const char *fmt, ...)
 {
@@ -29,21 +30,9 @@ int fail(const char *fmt, ...)
     va_end(ap);
     return 1;
 }
+const char *last_error() { return g_err; }
 
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) return fail("%s: %s", #expr, hipGetErrorString(e_));            \
-    } while (0)
-
-struct DeviceCtx {
-    bool ready = false;
-    sea_ns_tables *ns = nullptr;
-    sea_cc_tables *cc = nullptr;
-    sea_gt_tables *gt = nullptr;
-    int n_cu = 256;
-};
-
+namespace {
 constexpr int kMaxDev = 64;
 DeviceCtx g_ctx[kMaxDev];
 std::mutex g_mu;
@@ -60,8 +49,8 @@ void host_tables()
     sea_build_gt_tables(&g_gt_host);
     g_host_ready = true;
 }
+} // namespace
 
-/* per-device context for the CURRENT device; uploads the constant tables on first use */
 int ctx(DeviceCtx **out)
 {
     int dev = -1;
@@ -88,98 +77,6 @@ int ctx(DeviceCtx **out)
     return 0;
 }
 
-template <typename T>
-struct DevBuf {
-    T *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n * sizeof(T) + 16); }
-};
-
-long long align8(long long v) { return (v + 7) & ~7LL; }
-
-/* Grow-only workspace of the host-buffer entry points, one per calling host thread (the reference's
- * Windows batch tool calls etsi_denoise from N threads): pinned staging, device buffers, a private
- * stream.  A drop-in call then costs copies + one launch, no hipMalloc / hipFree. */
-struct HostWs {
-    short *h_in = nullptr, *h_out = nullptr; /* pinned */
-    short *d_in = nullptr, *d_out = nullptr;
-    long long *h_meta = nullptr, *d_meta = nullptr; /* offsets | lengths */
-    int *h_order = nullptr, *d_order = nullptr;
-    size_t cap = 0, cap_utt = 0;
-    hipStream_t stream = nullptr;
-    int device = -1; /* the device every buffer and the stream belong to */
-    ~HostWs() { release(); }
-    void release_samples()
-    {
-        if (h_in) (void)hipHostFree(h_in);
-        if (h_out) (void)hipHostFree(h_out);
-        if (d_in) (void)hipFree(d_in);
-        if (d_out) (void)hipFree(d_out);
-        h_in = h_out = d_in = d_out = nullptr;
-        cap = 0;
-    }
-    void release_meta()
-    {
-        if (h_meta) (void)hipHostFree(h_meta);
-        if (h_order) (void)hipHostFree(h_order);
-        if (d_meta) (void)hipFree(d_meta);
-        if (d_order) (void)hipFree(d_order);
-        h_meta = d_meta = nullptr;
-        h_order = d_order = nullptr;
-        cap_utt = 0;
-    }
-    void release()
-    {
-        release_samples();
-        release_meta();
-        if (stream) (void)hipStreamDestroy(stream);
-        stream = nullptr;
-        device = -1;
-    }
-    /* A failed allocation leaves the group it belongs to empty (nothing half-allocated is kept). */
-    hipError_t ensure(size_t samples, size_t n_utt)
-    {
-        hipError_t e;
-        int dev = -1;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if (dev != device) { /* the thread moved to another device (hipSetDevice): nothing of the old one is usable */
-            if (device >= 0) {
-                (void)hipSetDevice(device);
-                release();
-                (void)hipSetDevice(dev);
-            }
-            device = dev;
-        }
-        if (!stream && (e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)) != hipSuccess) return e;
-        if (samples > cap) {
-            const size_t want = samples + samples / 4 + 4096;
-            release_samples();
-            if ((e = hipHostMalloc((void **)&h_in, want * sizeof(short), hipHostMallocDefault)) != hipSuccess ||
-                (e = hipHostMalloc((void **)&h_out, want * sizeof(short), hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc((void **)&d_in, want * sizeof(short) + 16)) != hipSuccess ||
-                (e = hipMalloc((void **)&d_out, want * sizeof(short) + 16)) != hipSuccess) {
-                release_samples();
-                return e;
-            }
-            cap = want;
-        }
-        if (n_utt > cap_utt) {
-            const size_t want = n_utt + n_utt / 4 + 16;
-            release_meta();
-            if ((e = hipHostMalloc((void **)&h_meta, 2 * want * sizeof(long long), hipHostMallocDefault)) != hipSuccess ||
-                (e = hipHostMalloc((void **)&h_order, want * sizeof(int), hipHostMallocDefault)) != hipSuccess ||
-                (e = hipMalloc((void **)&d_meta, 2 * want * sizeof(long long))) != hipSuccess ||
-                (e = hipMalloc((void **)&d_order, want * sizeof(int))) != hipSuccess) {
-                release_meta();
-                return e;
-            }
-            cap_utt = want;
-        }
-        return hipSuccess;
-    }
-};
-thread_local HostWs t_ws;
-
 /* launch order of the utterance-per-workgroup kernels: longest first, every other row of n_cu reversed
  * (workgroups b, b + n_cu, ... share a CU; see speech_enhancement_amd/engine.py::launch_order) */
 void launch_order(const long long *lens, int n, int n_cu, int *order)
@@ -194,11 +91,49 @@ void launch_order(const long long *lens, int n, int n_cu, int *order)
     for (int i = 0; i < n; ++i) order[i] = idx[i];
 }
 
-} // namespace
+void gammatone_host_tables(float *cf64, float *bw64, float *midEar64)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    host_tables();
+    memcpy(cf64, g_gt_host.cf, sizeof g_gt_host.cf);
+    memcpy(bw64, g_gt_host.bw, sizeof g_gt_host.bw);
+    memcpy(midEar64, g_gt_host.midEar, sizeof g_gt_host.midEar);
+}
+
+/* Three forms of the same arithmetic (identical results), chosen by how many utterances share a CU:
+ *   <= 2 per CU  six waves per utterance: shortest frame period (the run time is one utterance's
+ *                chain of frames)                                     SEA_NS_KERNEL=pipe6
+ *   <= 4 per CU  four waves, transform address tables in VGPRs       SEA_NS_KERNEL=pipe
+ *   more         four waves, tables in LDS: six workgroups per CU     SEA_NS_KERNEL=big
+ * SEA_NS_KERNEL=single: one wave per utterance (the streaming plug-in's kernel), for A/B. */
+int ns_pick_form(int n_inflight, int n_cu)
+{
+    const int forced = sea_ns_kernel_form(-1);
+    return forced ? forced : (n_inflight <= 2 * n_cu ? 3 : (n_inflight <= 4 * n_cu ? 2 : 4));
+}
+
+int ns_launch(const sea::NsBatchArgs &a, int form, hipStream_t stream)
+{
+    if (a.n_utt <= 0) return 0;
+    if (form == 1)
+        hipLaunchKernelGGL(sea::ns_denoise_kernel, dim3(a.n_utt), dim3(64), 0, stream, a);
+    else if (form == 3)
+        hipLaunchKernelGGL(sea::ns_denoise_pipe6_kernel, dim3(a.n_utt), dim3(384), 0, stream, a);
+    else if (form == 4)
+        hipLaunchKernelGGL(sea::ns_denoise_pipe_big_kernel, dim3(a.n_utt), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(sea::ns_denoise_pipe_kernel, dim3(a.n_utt), dim3(256), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+} // namespace sea_capi
+
+using namespace sea_capi;
 
 extern "C" {
 
-const char *sea_last_error(void) { return g_err; }
+const char *sea_last_error(void) { return last_error(); }
 const char *sea_version(void) { return "sea_mi355x 0.1 (gfx950)"; }
 
 int sea_device_count(void)
@@ -226,11 +161,7 @@ int sea_tables_host(float *sigWindow200, float *irWindow17, float *idct25x25, in
 
 int sea_gammatone_channels(float *cf64, float *bw64, float *midEar64)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
-    host_tables();
-    memcpy(cf64, g_gt_host.cf, sizeof g_gt_host.cf);
-    memcpy(bw64, g_gt_host.bw, sizeof g_gt_host.bw);
-    memcpy(midEar64, g_gt_host.midEar, sizeof g_gt_host.midEar);
+    gammatone_host_tables(cf64, bw64, midEar64);
     return 0;
 }
 
@@ -276,26 +207,9 @@ int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
     a.first_out = d_first_out;
     a.tables = c->ns;
     a.n_utt = n_utt;
-    /* Three forms of the same arithmetic (identical results), chosen by how many utterances share a CU:
-     *   <= 2 per CU  six waves per utterance: shortest frame period (the run time is one utterance's
-     *                chain of frames)                                     SEA_NS_KERNEL=pipe6
-     *   <= 4 per CU  four waves, transform address tables in VGPRs       SEA_NS_KERNEL=pipe
-     *   more         four waves, tables in LDS: six workgroups per CU     SEA_NS_KERNEL=big
-     * SEA_NS_KERNEL=single: one wave per utterance (the streaming plug-in's kernel), for A/B. */
-    const int forced = ns_form();
-    const int form = forced ? forced : (n_utt <= 2 * c->n_cu ? 3 : (n_utt <= 4 * c->n_cu ? 2 : 4));
-    if (form == 1)
-        hipLaunchKernelGGL(sea::ns_denoise_kernel, dim3(n_utt), dim3(64), 0, (hipStream_t)stream, a);
-    else if (form == 3)
-        hipLaunchKernelGGL(sea::ns_denoise_pipe6_kernel, dim3(n_utt), dim3(384), 0, (hipStream_t)stream, a);
-    else if (form == 4)
-        hipLaunchKernelGGL(sea::ns_denoise_pipe_big_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
-    else {
-        a.prio_row = (d_order && n_utt > c->n_cu) ? c->n_cu : 0; /* rows of the longest-first launch order */
-        hipLaunchKernelGGL(sea::ns_denoise_pipe_kernel, dim3(n_utt), dim3(256), 0, (hipStream_t)stream, a);
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    const int form = ns_pick_form(n_utt, c->n_cu);
+    if (form == 2) a.prio_row = (d_order && n_utt > c->n_cu) ? c->n_cu : 0; /* rows of the longest-first launch order */
+    return ns_launch(a, form, (hipStream_t)stream);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -414,51 +328,13 @@ int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const
     return 0;
 }
 
-/* ------------------------------------------------------------------------------------------- */
-int sea_denoise_utterances(const short *const *in, short *const *out, const long *lengths, int n_utt)
-{
-    if (n_utt <= 0) return 0;
-    DeviceCtx *dc;
-    if (ctx(&dc)) return 1;
-    long long total = 0;
-    for (int u = 0; u < n_utt; ++u) {
-        if (lengths[u] < 0) return fail("negative length for utterance %d", u);
-        total += align8(lengths[u]);
-    }
-    if (total == 0) return 0;
-    HostWs &w = t_ws;
-    HIP_TRY(w.ensure((size_t)total, (size_t)n_utt));
-    long long *offs = w.h_meta, *lens = w.h_meta + n_utt;
-    long long pos = 0;
-    for (int u = 0; u < n_utt; ++u) {
-        offs[u] = pos;
-        lens[u] = lengths[u];
-        memcpy(w.h_in + pos, in[u], (size_t)lens[u] * sizeof(short));
-        const long long pad = align8(lens[u]) - lens[u];
-        if (pad) memset(w.h_in + pos + lens[u], 0, (size_t)pad * sizeof(short));
-        pos += align8(lens[u]);
-    }
-    launch_order(lens, n_utt, dc->n_cu, w.h_order);
-    HIP_TRY(hipMemcpyAsync(w.d_in, w.h_in, (size_t)total * sizeof(short), hipMemcpyHostToDevice, w.stream));
-    HIP_TRY(hipMemcpyAsync(w.d_meta, w.h_meta, 2 * (size_t)n_utt * sizeof(long long), hipMemcpyHostToDevice, w.stream));
-    HIP_TRY(hipMemcpyAsync(w.d_order, w.h_order, (size_t)n_utt * sizeof(int), hipMemcpyHostToDevice, w.stream));
-    if (sea_ns_denoise_batch(w.d_in, w.d_out, nullptr, w.d_meta, w.d_meta + n_utt, n_utt > 1 ? w.d_order : nullptr,
-                             nullptr, n_utt, w.stream))
-        return 1;
-    HIP_TRY(hipMemcpyAsync(w.h_out, w.d_out, (size_t)total * sizeof(short), hipMemcpyDeviceToHost, w.stream));
-    HIP_TRY(hipStreamSynchronize(w.stream));
-    for (int u = 0; u < n_utt; ++u) /* the trailing partial frame stays untouched */
-        memcpy(out[u], w.h_out + offs[u], (size_t)(lens[u] / 80 * 80) * sizeof(short));
-    return 0;
-}
-
 int etsi_denoise(short *p_data, short *p_denoised, long i_frame)
 {
     const short *in[1] = {p_data};
     short *out[1] = {p_denoised};
     long len[1] = {i_frame};
     if (sea_denoise_utterances(in, out, len, 1)) {
-        fprintf(stderr, "ERROR:   etsi_denoise (MI355X): %s\r\n", g_err);
+        fprintf(stderr, "ERROR:   etsi_denoise (MI355X): %s\r\n", last_error());
         return 1; /* TRUE == fault, AdvFrontEnd.c:207-209 */
     }
     return 0;
@@ -496,7 +372,7 @@ void rfft(float *x, int n, int m)
               sea_rfft256_batch(d.p, d.p, 1, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess &&
               hipMemcpy(x, d.p, 256 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
     if (!ok) {
-        fprintf(stderr, "ERROR:   rfft (MI355X): no usable gfx950 device: %s\r\n", g_err);
+        fprintf(stderr, "ERROR:   rfft (MI355X): no usable gfx950 device: %s\r\n", last_error());
         abort();
     }
 }
@@ -579,92 +455,6 @@ int sea_resynth64(const short *in, long L, const float *mask, int F, int binary,
         return 1;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, dout.p, (size_t)L * sizeof(short), hipMemcpyDeviceToHost));
-    return 0;
-}
-
-/* One sub-batch [u0, u1) of sea_resynth_utterances: pack, upload, one launch, download. */
-static int resynth_sub_batch(const short *const *in, const long *lengths, const float *const *masks, int binary,
-                             short *const *out, int u0, int u1, float *d_inter)
-{
-    const int n = u1 - u0;
-    std::vector<long long> offs(n), lens(n), moffs(n);
-    long long total = 0, rows = 0;
-    auto nrows = [&](long L) { return (binary & 2) ? L / 160 : (L - 320) / 160 + 1; };
-    for (int k = 0; k < n; ++k) {
-        offs[k] = total;
-        lens[k] = lengths[u0 + k];
-        moffs[k] = rows;
-        total += align8(lens[k]);
-        rows += nrows(lengths[u0 + k]);
-    }
-    std::vector<short> pack((size_t)total, 0);
-    std::vector<float> mpack((size_t)rows * 64);
-    for (int k = 0; k < n; ++k) {
-        memcpy(&pack[(size_t)offs[k]], in[u0 + k], (size_t)lens[k] * sizeof(short));
-        memcpy(&mpack[(size_t)moffs[k] * 64], masks[u0 + k], (size_t)nrows(lengths[u0 + k]) * 64 * sizeof(float));
-    }
-    DevBuf<short> din, dout;
-    DevBuf<float> dmask;
-    DevBuf<long long> dmeta;
-    HIP_TRY(din.alloc((size_t)total));
-    HIP_TRY(dout.alloc((size_t)total));
-    HIP_TRY(dmask.alloc(mpack.size()));
-    HIP_TRY(dmeta.alloc(3 * (size_t)n));
-    HIP_TRY(hipMemcpy(din.p, pack.data(), (size_t)total * sizeof(short), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dmask.p, mpack.data(), mpack.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dmeta.p, offs.data(), n * sizeof(long long), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dmeta.p + n, lens.data(), n * sizeof(long long), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dmeta.p + 2 * n, moffs.data(), n * sizeof(long long), hipMemcpyHostToDevice));
-    if (sea_resynth64_batch(din.p, dout.p, dmeta.p, dmeta.p + n, dmask.p, dmeta.p + 2 * n, d_inter, nullptr, n, binary,
-                            nullptr))
-        return 1;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(pack.data(), dout.p, (size_t)total * sizeof(short), hipMemcpyDeviceToHost));
-    for (int k = 0; k < n; ++k) memcpy(out[u0 + k], &pack[(size_t)offs[k]], (size_t)lens[k] * sizeof(short));
-    return 0;
-}
-
-/* The [time][64] float intermediate costs 256 B of HBM per sample (~16 MB per 4-s utterance): the list is cut
- * into sub-batches whose scratch fits in 60 % of the HBM that is free right now (SEA_RESYNTH_SCRATCH_MB overrides
- * the budget), and ONE scratch allocation is reused by all of them.  The reference processes one utterance at a
- * time (resyth_64sub_ori/cpp/main.cpp:84-145); results do not depend on the cut. */
-int sea_resynth_utterances(const short *const *in, const long *lengths, const float *const *masks, int binary,
-                           short *const *out, int n_utt)
-{
-    if (n_utt <= 0) return 0;
-    DeviceCtx *c;
-    if (ctx(&c)) return 1;
-    long long largest = 0;
-    for (int u = 0; u < n_utt; ++u) {
-        if (lengths[u] < ((binary & 2) ? 160 : 320))
-            return fail("resynth: utterance %d has %ld samples (too short for one mask frame)", u, lengths[u]);
-        largest = std::max(largest, sea_resynth_scratch_bytes(align8(lengths[u]), 1));
-    }
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    long long budget = (long long)(free_b / 10 * 6);
-    if (const char *e = getenv("SEA_RESYNTH_SCRATCH_MB")) budget = atoll(e) * (1LL << 20);
-    if (budget < largest) budget = largest; /* one utterance must fit; hipMalloc reports it if it does not */
-    /* cut: greedy runs of consecutive utterances within the budget */
-    std::vector<int> cuts(1, 0);
-    long long run = 0, run_max = 0;
-    int run_n = 0;
-    for (int u = 0; u < n_utt; ++u) {
-        const long long need = sea_resynth_scratch_bytes(run + align8(lengths[u]), run_n + 1);
-        if (run_n > 0 && need > budget) {
-            cuts.push_back(u);
-            run = 0;
-            run_n = 0;
-        }
-        run += align8(lengths[u]);
-        run_n++;
-        run_max = std::max(run_max, sea_resynth_scratch_bytes(run, run_n));
-    }
-    cuts.push_back(n_utt);
-    DevBuf<float> dinter;
-    HIP_TRY(dinter.alloc((size_t)run_max / sizeof(float)));
-    for (size_t k = 0; k + 1 < cuts.size(); ++k)
-        if (resynth_sub_batch(in, lengths, masks, binary, out, cuts[k], cuts[k + 1], dinter.p)) return 1;
     return 0;
 }
 
@@ -799,7 +589,7 @@ int sea_ns_stream_push(sea_ns_stream *s, const float *in80, float *out80)
 {
     DeviceCtx *c;
     if (!s || ctx(&c)) {
-        fprintf(stderr, "ERROR:   DoNoiseSup (MI355X): %s\r\n", s ? g_err : "NULL stream");
+        fprintf(stderr, "ERROR:   DoNoiseSup (MI355X): %s\r\n", s ? last_error() : "NULL stream");
         exit(1); /* the reference's DoNoiseSup path ends the process on failure (NoiseSup.c:983-987: exit(0));
                   * a device fault must not look like success to the caller's shell, so the status is non-zero */
     }

@@ -1,0 +1,650 @@
+/*
+ * hostpipe.hip -- the host-buffer batch entry points as a copy / compute pipeline.
+ *
+ *   sea_denoise_utterances   what etsi/cpp/main.cpp:43-67 does per file (read, etsi_denoise, write) and
+ *                            function/20141106_speech_enhancement/aurora_speech_enhancement/aurora_speech_enhancement.cpp:25-80
+ *                            does from a thread pool, for a whole list of utterances in host memory
+ *   sea_resynth_utterances   the same for resynth() (resyth_64sub_ori/cpp/main.cpp:84-145)
+ *
+ * PCIe is the slow link of these entry points (160 B per NoiseSup frame each way against 320 B of HBM traffic
+ * on the device), so the list is cut into chunks that travel down a pipeline:
+ *
+ *   pool threads   pack chunk k+1 into pinned staging            | unpack chunk k-1 into the caller's buffers
+ *   stream k % S   H2D chunk k -> kernel over chunk k -> D2H chunk k
+ *
+ * Utterances are sorted longest first (the kernels' run time is their longest utterance's chain of frames), the
+ * chunks are contiguous ranges of that order, every chunk is one launch on its own slice of ONE device buffer.
+ * Results do not depend on the cut: an utterance is processed by one workgroup whatever its neighbours.
+ * Staging, device buffers, streams and events are grow-only and belong to the calling host thread (the reference's
+ * batch tool calls etsi_denoise from N threads); the packing threads are one process-wide pool.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "capi_internal.h"
+
+using namespace sea_capi;
+
+namespace {
+
+/* ---- packing threads ------------------------------------------------------------------------------ */
+class Pool {
+  public:
+    static Pool &get()
+    {
+        static Pool p;
+        return p;
+    }
+    int size() const { return (int)th_.size(); }
+    void submit(std::function<void()> f)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            q_.push_back(std::move(f));
+        }
+        cv_.notify_one();
+    }
+
+  private:
+    Pool()
+    {
+        int n = 0;
+        if (const char *e = getenv("SEA_HOST_THREADS")) n = atoi(e);
+        if (n <= 0) {
+            const unsigned hw = std::thread::hardware_concurrency();
+            n = hw > 2 ? (int)std::min(8u, hw - 1) : 1;
+        }
+        for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void run()
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return; /* stop requested and nothing left */
+                f = std::move(q_.front());
+                q_.pop_front();
+            }
+            f();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> q_;
+    bool stop_ = false;
+};
+
+/* counts outstanding tasks; wait() returns when all are done */
+struct Latch {
+    std::mutex m;
+    std::condition_variable cv;
+    int pending = 0;
+    void add(int n)
+    {
+        std::lock_guard<std::mutex> lk(m);
+        pending += n;
+    }
+    void done()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        if (--pending == 0) cv.notify_all();
+    }
+    bool ready()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        return pending == 0;
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return pending == 0; });
+    }
+    template <class Rep, class Period>
+    bool wait_for(std::chrono::duration<Rep, Period> d)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        return cv.wait_for(lk, d, [this] { return pending == 0; });
+    }
+};
+
+/* copies [j0, j1) of a job list on the pool (or inline when the job is small), cut into ~1 MB tasks */
+template <class Copy>
+void run_copies(int j0, int j1, const long long *bytes_prefix, Latch *chunk, Latch *all, bool inline_, Copy copy)
+{
+    if (j0 >= j1) return;
+    if (inline_) {
+        for (int j = j0; j < j1; ++j) copy(j);
+        return;
+    }
+    const long long kTask = 1 << 20;
+    int a = j0;
+    while (a < j1) {
+        int b = a + 1;
+        while (b < j1 && bytes_prefix[b] - bytes_prefix[a] < kTask) ++b;
+        chunk->add(1);
+        all->add(1);
+        Pool::get().submit([=] {
+            for (int j = a; j < b; ++j) copy(j);
+            chunk->done();
+            all->done();
+        });
+        a = b;
+    }
+}
+
+/* ---- per-thread workspace -------------------------------------------------------------------------- */
+constexpr int kMaxStreams = 8;
+int n_streams()
+{
+    static const int n = [] {
+        const char *e = getenv("SEA_HOST_STREAMS");
+        const int v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : (v > kMaxStreams ? kMaxStreams : v);
+    }();
+    return n;
+}
+#define kStreams n_streams()
+constexpr int kMaxChunks = 64;
+
+template <class T>
+struct Grow { /* one pinned + one device buffer of the same size, grow-only */
+    T *h = nullptr, *d = nullptr;
+    size_t cap = 0;
+    void release()
+    {
+        if (h) (void)hipHostFree(h);
+        if (d) (void)hipFree(d);
+        h = d = nullptr;
+        cap = 0;
+    }
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        release();
+        const size_t want = n + n / 4 + 4096;
+        hipError_t e = hipHostMalloc((void **)&h, want * sizeof(T), hipHostMallocDefault); /* (write-combined staging: no gain) */
+        if (e == hipSuccess) e = hipMalloc((void **)&d, want * sizeof(T) + 16);
+        if (e != hipSuccess) {
+            release();
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+};
+
+struct PipeWs {
+    Grow<short> in, out;
+    Grow<float> mask;      /* resynth: mask rows */
+    Grow<long long> meta;  /* offsets | lengths | mask offsets, in launch order */
+    float *d_inter = nullptr; /* resynth scratch */
+    size_t inter_bytes = 0;
+    hipStream_t stream[kMaxStreams] = {};
+    hipEvent_t ev_meta = nullptr, ev_done[kMaxChunks] = {}, ev_kernel[kMaxChunks] = {}, ev_h2d[kMaxChunks] = {};
+    int device = -1;
+    ~PipeWs() { release(); }
+    void release()
+    {
+        int cur = -1;
+        const bool sw = device >= 0 && hipGetDevice(&cur) == hipSuccess && cur != device;
+        if (sw) (void)hipSetDevice(device); /* the buffers belong to `device`, whatever the thread uses now */
+        in.release();
+        out.release();
+        mask.release();
+        meta.release();
+        if (d_inter) (void)hipFree(d_inter);
+        d_inter = nullptr;
+        inter_bytes = 0;
+        for (auto &s : stream) {
+            if (s) (void)hipStreamDestroy(s);
+            s = nullptr;
+        }
+        if (ev_meta) (void)hipEventDestroy(ev_meta);
+        ev_meta = nullptr;
+        for (auto &e : ev_done) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+        for (auto &e : ev_kernel) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+        for (auto &e : ev_h2d) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+        if (sw) (void)hipSetDevice(cur);
+        device = -1;
+    }
+    hipError_t bind()
+    {
+        int dev = -1;
+        hipError_t e;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if (dev != device) { /* the thread moved to another device: nothing of the old one is usable */
+            if (device >= 0) release();
+            device = dev;
+        }
+        for (int i = 0; i < kStreams; ++i)
+            if (!stream[i] && (e = hipStreamCreateWithFlags(&stream[i], hipStreamNonBlocking)) != hipSuccess) return e;
+        if (!ev_meta && (e = hipEventCreateWithFlags(&ev_meta, hipEventDisableTiming)) != hipSuccess) return e;
+        for (auto &ev : ev_done)
+            if (!ev && (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
+        for (auto &ev : ev_kernel)
+            if (!ev && (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
+        for (auto &ev : ev_h2d)
+            if (!ev && (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
+        return hipSuccess;
+    }
+    hipError_t ensure_inter(size_t bytes)
+    {
+        if (bytes <= inter_bytes) return hipSuccess;
+        if (d_inter) (void)hipFree(d_inter);
+        d_inter = nullptr;
+        inter_bytes = 0;
+        hipError_t e = hipMalloc((void **)&d_inter, bytes + 16);
+        if (e == hipSuccess) inter_bytes = bytes;
+        return e;
+    }
+    void drain()
+    {
+        for (auto &s : stream)
+            if (s) (void)hipStreamSynchronize(s);
+    }
+};
+thread_local PipeWs t_ws;
+
+/* On every exit path: no pool task may outlive the buffers it copies from / to, no stream may still be copying. */
+struct Scope {
+    Latch all;
+    PipeWs *ws;
+    bool ok = false;
+    explicit Scope(PipeWs *w) : ws(w) {}
+    ~Scope()
+    {
+        all.wait();
+        if (!ok) ws->drain();
+    }
+};
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+long long env_mb(const char *name, long long dflt)
+{
+    if (const char *e = getenv(name)) {
+        const long long v = atoll(e);
+        if (v > 0) return v;
+    }
+    return dflt;
+}
+
+/* cut the (sorted) list into at most max_chunks contiguous chunks of about `target` weight each */
+std::vector<int> cut_chunks(const std::vector<long long> &weight_prefix, int n, long long target, int max_chunks)
+{
+    const long long total = weight_prefix[n];
+    int nchunk = (int)std::min<long long>(max_chunks, std::max<long long>(1, (total + target - 1) / target));
+    nchunk = std::min(nchunk, n);
+    std::vector<int> cuts(1, 0);
+    for (int k = 1; k < nchunk; ++k) {
+        const long long want = total * k / nchunk;
+        int j = (int)(std::lower_bound(weight_prefix.begin(), weight_prefix.begin() + n + 1, want) - weight_prefix.begin());
+        j = std::max(j, cuts.back() + 1);
+        if (j >= n) break;
+        cuts.push_back(j);
+    }
+    cuts.push_back(n);
+    return cuts;
+}
+
+} // namespace
+
+extern "C" {
+
+int sea_host_threads(void) { return Pool::get().size(); }
+
+/* ---------------------------------------------------------------------------------------------------- */
+int sea_denoise_utterances(const short *const *in, short *const *out, const long *lengths, int n_utt)
+{
+    if (n_utt <= 0) return 0;
+    DeviceCtx *dc;
+    if (ctx(&dc)) return 1;
+    for (int u = 0; u < n_utt; ++u)
+        if (lengths[u] < 0) return fail("negative length for utterance %d", u);
+    /* launch order: longest first */
+    std::vector<int> idx(n_utt);
+    for (int i = 0; i < n_utt; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return lengths[a] > lengths[b]; });
+    std::vector<long long> pre(n_utt + 1, 0); /* packed offset of sorted position j, in samples */
+    for (int j = 0; j < n_utt; ++j) pre[j + 1] = pre[j] + align8(lengths[idx[j]]);
+    const long long total = pre[n_utt];
+    if (total == 0) return 0;
+
+    PipeWs &w = t_ws;
+    HIP_TRY(w.bind());
+    HIP_TRY(w.in.ensure((size_t)total));
+    HIP_TRY(w.out.ensure((size_t)total));
+    HIP_TRY(w.meta.ensure(2 * (size_t)n_utt));
+    long long *offs = w.meta.h, *lens = w.meta.h + n_utt;
+    for (int j = 0; j < n_utt; ++j) {
+        offs[j] = pre[j];
+        lens[j] = lengths[idx[j]];
+    }
+    /* Chunks (small lists: one chunk, packed by the calling thread).  Default: a third of the list each -- measured on
+     * the 1024-utterance bench corpus (tools/host_sweep.sh): kernels launched on different streams do overlap, but a
+     * launch runs as long as its longest utterance's chain of frames whatever its size and several small launches side
+     * by side fill the chip worse than one large one, so few large chunks win (3 chunks 6.3 ms, 6 chunks 7.4 ms,
+     * 16 chunks 16.5 ms; one chunk = no overlap 10.4 ms).  SEA_HOST_CHUNK_MB sets the chunk size in MB of int16. */
+    const long long chunk_samples = getenv("SEA_HOST_CHUNK_MB") ? env_mb("SEA_HOST_CHUNK_MB", 24) * (1 << 20) / 2
+                                                                : std::max<long long>((total + 2) / 3, 1 << 20);
+    const bool small = total * 2 < (2 << 20) || n_utt == 1 || Pool::get().size() <= 1;
+    const std::vector<int> cuts = small ? std::vector<int>{0, n_utt} : cut_chunks(pre, n_utt, chunk_samples, kMaxChunks);
+    const int nchunk = (int)cuts.size() - 1;
+    const int form = ns_pick_form(n_utt, dc->n_cu);
+    /* SEA_HOST_ZEROCOPY=o (experiment kept for other hosts): the kernel's stores go straight to the pinned output
+     * staging over PCIe (160 B per frame and utterance), no D2H phase.  Measured here: such stores reach ~24 GB/s
+     * against 52 GB/s of a D2H copy and slow the kernel down by as much as the copy phase they save. */
+    const char *zc = getenv("SEA_HOST_ZEROCOPY");
+    const bool zc_out = zc ? (strchr(zc, 'o') != nullptr) : false;
+    short *d_out = w.out.d;
+    if (zc_out) HIP_TRY(hipHostGetDevicePointer((void **)&d_out, w.out.h, 0));
+    /* issue order of the chunks (chunk 0 holds the longest utterances; SEA_HOST_ORDER=desc|asc|mix, measured within
+     * 5 % of each other, longest first best) */
+    std::vector<int> seq(nchunk);
+    {
+        const char *o = getenv("SEA_HOST_ORDER");
+        const int mode = (o && !strcmp(o, "mix")) ? 2 : ((o && !strcmp(o, "asc")) ? 1 : 0); /* default: longest first */
+        for (int i = 0, lo = 0, hi = nchunk - 1; i < nchunk; ++i)
+            seq[i] = mode == 0 ? i : (mode == 1 ? nchunk - 1 - i : ((i & 1) ? hi-- : lo++));
+    }
+
+    std::vector<Latch> packed(nchunk), unpacked(nchunk);
+    Scope scope(&w);
+    short *h_in = w.in.h, *h_out = w.out.h;
+    std::vector<long long> bytes_pre(pre); /* task sizing */
+    for (auto &b : bytes_pre) b *= 2;
+    const long long *bp = bytes_pre.data();
+    const int *ix = idx.data();
+    for (int i = 0; i < nchunk; ++i) {
+        const int k = seq[i];
+        run_copies(cuts[k], cuts[k + 1], bp, &packed[k], &scope.all, small, [=](int j) {
+            const long long L = lens[j];
+            memcpy(h_in + offs[j], in[ix[j]], (size_t)L * sizeof(short));
+            const long long pad = align8(L) - L;
+            if (pad) memset(h_in + offs[j] + L, 0, (size_t)pad * sizeof(short));
+        });
+    }
+    HIP_TRY(hipMemcpyAsync(w.meta.d, w.meta.h, 2 * (size_t)n_utt * sizeof(long long), hipMemcpyHostToDevice, w.stream[0]));
+    HIP_TRY(hipEventRecord(w.ev_meta, w.stream[0]));
+
+    const bool trace = getenv("SEA_HOST_TRACE") != nullptr;
+    /* timing experiments only: from the second call on skip the PCIe copies (the device works on the first call's input) */
+    static std::atomic<int> n_calls{0};
+    const bool nocopy = getenv("SEA_HOST_DEBUG_NOCOPY") != nullptr && n_calls++ > 0;
+    const double t0 = now_ms();
+    std::vector<hipEvent_t> tev; /* trace only: base, then (start, h2d, kernel, d2h) per chunk */
+    if (trace) {
+        tev.resize(1 + 4 * nchunk);
+        for (auto &e : tev) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventRecord(tev[0], w.stream[0]));
+    }
+    /* Event-driven: a copy is only handed to the runtime when everything it depends on has finished.  The copy
+     * engines' queues are in order, so a D2H copy queued behind its still-running kernel would hold up the H2D copies
+     * of later chunks (measured: chunk k+2's upload waited for chunk k's kernel). */
+    enum { kWaitPack, kComputing, kDownloading, kUnpacking };
+    std::vector<char> state(nchunk, kWaitPack);
+    int next = 0, finished = 0;
+    while (finished < nchunk) {
+        bool progressed = false;
+        /* one upload at a time: concurrent uploads share the link, and the first kernel should start as early as it can */
+        if (next < nchunk && packed[seq[next]].ready() &&
+            (next == 0 || hipEventQuery(w.ev_h2d[seq[next - 1]]) == hipSuccess)) {
+            const int k = seq[next], i = next++;
+            hipStream_t s = w.stream[i % kStreams];
+            const int u0 = cuts[k], n = cuts[k + 1] - cuts[k];
+            const long long o0 = pre[u0], cnt = pre[cuts[k + 1]] - o0;
+            if (trace) fprintf(stderr, "[hostpipe] %7.3f ms  chunk %d packed (%d utterances, %.1f MB), issuing\n", now_ms() - t0, k, n, cnt * 2 / 1048576.0);
+            if (i > 0 && i < kStreams) HIP_TRY(hipStreamWaitEvent(s, w.ev_meta, 0));
+            if (trace) HIP_TRY(hipEventRecord(tev[1 + 4 * k], s));
+            if (!nocopy)
+                HIP_TRY(hipMemcpyAsync(w.in.d + o0, h_in + o0, (size_t)cnt * sizeof(short), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipEventRecord(w.ev_h2d[k], s));
+            if (trace) HIP_TRY(hipEventRecord(tev[2 + 4 * k], s));
+            sea::NsBatchArgs a = {};
+            a.in = w.in.d;
+            a.out = d_out;
+            a.offsets = w.meta.d + u0;
+            a.lengths = w.meta.d + n_utt + u0;
+            a.tables = dc->ns;
+            a.n_utt = n;
+            if (form == 2 && n_utt > dc->n_cu) { /* issue priority by rows of the whole list, as the one-launch form has it */
+                a.prio_row = dc->n_cu;
+                a.prio_base = u0 / dc->n_cu;
+            }
+            if (ns_launch(a, form, s)) return 1;
+            if (trace) HIP_TRY(hipEventRecord(tev[3 + 4 * k], s));
+            HIP_TRY(hipEventRecord(w.ev_kernel[k], s));
+            state[k] = kComputing;
+            progressed = true;
+        }
+        for (int i = 0; i < next; ++i) {
+            const int k = seq[i];
+            if (state[k] == kComputing && hipEventQuery(w.ev_kernel[k]) == hipSuccess) {
+                hipStream_t s = w.stream[i % kStreams];
+                const long long o0 = pre[cuts[k]], cnt = pre[cuts[k + 1]] - o0;
+                if (!zc_out && !nocopy) HIP_TRY(hipMemcpyAsync(h_out + o0, w.out.d + o0, (size_t)cnt * sizeof(short), hipMemcpyDeviceToHost, s));
+                if (trace) HIP_TRY(hipEventRecord(tev[4 + 4 * k], s));
+                HIP_TRY(hipEventRecord(w.ev_done[k], s));
+                state[k] = kDownloading;
+                progressed = true;
+            }
+            if (state[k] == kDownloading && hipEventQuery(w.ev_done[k]) == hipSuccess) {
+                if (trace) fprintf(stderr, "[hostpipe] %7.3f ms  chunk %d done on the device, unpacking\n", now_ms() - t0, k);
+                run_copies(cuts[k], cuts[k + 1], bp, &unpacked[k], &scope.all, small, [=](int j) {
+                    /* the trailing partial frame stays untouched */
+                    memcpy(out[ix[j]], h_out + offs[j], (size_t)(lens[j] / 80 * 80) * sizeof(short));
+                });
+                state[k] = kUnpacking;
+                finished++;
+                progressed = true;
+            }
+        }
+        if (!progressed) {
+            if (next < nchunk && !packed[seq[next]].ready()) packed[seq[next]].wait_for(std::chrono::microseconds(30));
+            else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+    scope.all.wait();
+    if (trace) {
+        fprintf(stderr, "[hostpipe] %7.3f ms  all unpacked\n", now_ms() - t0);
+        for (int k = 0; k < nchunk; ++k) {
+            float t[4];
+            for (int q = 0; q < 4; ++q) (void)hipEventElapsedTime(&t[q], tev[0], tev[1 + 4 * k + q]);
+            fprintf(stderr, "[hostpipe] device clock, chunk %d: start %.3f  h2d done %.3f  kernel done %.3f  d2h done %.3f ms\n", k,
+                    t[0], t[1], t[2], t[3]);
+        }
+        for (auto &e : tev) (void)hipEventDestroy(e);
+    }
+    scope.ok = true;
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* The [time][64] float intermediate costs 256 B of HBM per sample (~16 MB per 4-s utterance).  The chunks of the
+ * pipeline run on kStreams streams, each with a scratch region of its own, sized so that all regions together fit
+ * in 60 % of the HBM that is free right now (SEA_RESYNTH_SCRATCH_MB overrides the budget); a chunk is at most what
+ * one region holds.  The reference processes one utterance at a time (resyth_64sub_ori/cpp/main.cpp:84-145);
+ * results do not depend on the cut. */
+int sea_resynth_utterances(const short *const *in, const long *lengths, const float *const *masks, int binary,
+                           short *const *out, int n_utt)
+{
+    if (n_utt <= 0) return 0;
+    DeviceCtx *dc;
+    if (ctx(&dc)) return 1;
+    auto nrows = [&](long L) -> long long { return (binary & 2) ? L / 160 : (L - 320) / 160 + 1; };
+    long long largest = 0;
+    for (int u = 0; u < n_utt; ++u) {
+        if (lengths[u] < ((binary & 2) ? 160 : 320))
+            return fail("resynth: utterance %d has %ld samples (too short for one mask frame)", u, lengths[u]);
+        largest = std::max(largest, sea_resynth_scratch_bytes(align8(lengths[u]), 1));
+    }
+    std::vector<int> idx(n_utt);
+    for (int i = 0; i < n_utt; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return lengths[a] > lengths[b]; });
+    std::vector<long long> pre(n_utt + 1, 0), rpre(n_utt + 1, 0);
+    for (int j = 0; j < n_utt; ++j) {
+        pre[j + 1] = pre[j] + align8(lengths[idx[j]]);
+        rpre[j + 1] = rpre[j] + nrows(lengths[idx[j]]);
+    }
+    const long long total = pre[n_utt], rows = rpre[n_utt];
+
+    PipeWs &w = t_ws;
+    HIP_TRY(w.bind());
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    long long budget = (long long)((free_b + w.inter_bytes) / 10 * 6);
+    if (const char *e = getenv("SEA_RESYNTH_SCRATCH_MB")) budget = atoll(e) * (1LL << 20);
+    /* regions: as many streams as there will be chunks, each at least one utterance */
+    long long region = std::max(largest, budget / kStreams);
+    /* chunk = at most a region's worth of scratch and about SEA_HOST_CHUNK_MB of (int16 + mask) input */
+    std::vector<int> cuts(1, 0);
+    {
+        /* default: about a quarter of the list per chunk (few large launches fill the chip better than many small ones) */
+        const long long in_target = getenv("SEA_HOST_CHUNK_MB") ? env_mb("SEA_HOST_CHUNK_MB", 24) * (1 << 20)
+                                                                : std::max<long long>((total * 4 + rows * 256 + 3) / 4, 1 << 20);
+        long long run = 0, run_bytes = 0;
+        int run_n = 0;
+        for (int j = 0; j < n_utt; ++j) {
+            const long long Lp = align8(lengths[idx[j]]);
+            const long long b = Lp * 4 + nrows(lengths[idx[j]]) * 256;
+            const bool over = sea_resynth_scratch_bytes(run + Lp, run_n + 1) > region || run_bytes + b > in_target ||
+                              run_n >= 4 * dc->n_cu;
+            if (run_n > 0 && over && (int)cuts.size() < kMaxChunks) {
+                cuts.push_back(j);
+                run = run_bytes = 0;
+                run_n = 0;
+            }
+            run += Lp;
+            run_bytes += b;
+            run_n++;
+        }
+        cuts.push_back(n_utt);
+    }
+    const int nchunk = (int)cuts.size() - 1;
+    /* a region is as large as the largest chunk (the last one can exceed the budget share when kMaxChunks is reached:
+     * hipMalloc then reports what does not fit) */
+    region = 0;
+    for (int k = 0; k < nchunk; ++k)
+        region = std::max(region, sea_resynth_scratch_bytes(pre[cuts[k + 1]] - pre[cuts[k]], cuts[k + 1] - cuts[k]));
+    const int nregion = std::min(nchunk, kStreams);
+    HIP_TRY(w.ensure_inter((size_t)region * nregion));
+    HIP_TRY(w.in.ensure((size_t)total));
+    HIP_TRY(w.out.ensure((size_t)total));
+    HIP_TRY(w.mask.ensure((size_t)rows * 64));
+    HIP_TRY(w.meta.ensure(3 * (size_t)n_utt));
+    long long *offs = w.meta.h, *lens = w.meta.h + n_utt, *moffs = w.meta.h + 2 * n_utt;
+    for (int k = 0; k < nchunk; ++k)
+        for (int j = cuts[k]; j < cuts[k + 1]; ++j) {
+            /* sample offsets are relative to the chunk (the scratch region is indexed by them), buffers are sliced */
+            offs[j] = pre[j] - pre[cuts[k]];
+            lens[j] = lengths[idx[j]];
+            moffs[j] = rpre[j] - rpre[cuts[k]];
+        }
+    const bool small = (total * 4 + rows * 256) < (2 << 20) || n_utt == 1 || Pool::get().size() <= 1;
+
+    std::vector<Latch> packed(nchunk), unpacked(nchunk);
+    Scope scope(&w);
+    short *h_in = w.in.h, *h_out = w.out.h;
+    float *h_mask = w.mask.h;
+    std::vector<long long> bytes_pre(n_utt + 1);
+    for (int j = 0; j <= n_utt; ++j) bytes_pre[j] = pre[j] * 2 + rpre[j] * 256;
+    const long long *bp = bytes_pre.data(), *prep = pre.data(), *rprep = rpre.data();
+    const int *ix = idx.data();
+    for (int k = 0; k < nchunk; ++k)
+        run_copies(cuts[k], cuts[k + 1], bp, &packed[k], &scope.all, small, [=](int j) {
+            const long long L = lens[j];
+            memcpy(h_in + prep[j], in[ix[j]], (size_t)L * sizeof(short));
+            const long long pad = align8(L) - L;
+            if (pad) memset(h_in + prep[j] + L, 0, (size_t)pad * sizeof(short));
+            memcpy(h_mask + rprep[j] * 64, masks[ix[j]], (size_t)(rprep[j + 1] - rprep[j]) * 64 * sizeof(float));
+        });
+    HIP_TRY(hipMemcpyAsync(w.meta.d, w.meta.h, 3 * (size_t)n_utt * sizeof(long long), hipMemcpyHostToDevice, w.stream[0]));
+    HIP_TRY(hipEventRecord(w.ev_meta, w.stream[0]));
+
+    /* event-driven, as in sea_denoise_utterances: the D2H copy of a chunk is issued when its kernel has finished */
+    enum { kWaitPack, kComputing, kDownloading, kUnpacking };
+    std::vector<char> state(nchunk, kWaitPack);
+    int next = 0, finished = 0;
+    while (finished < nchunk) {
+        bool progressed = false;
+        /* a chunk reuses the scratch region and the stream of chunk k - nregion: stream order protects the region */
+        if (next < nchunk && packed[next].ready()) {
+            const int k = next++, r = k % nregion;
+            hipStream_t s = w.stream[r];
+            const int u0 = cuts[k], n = cuts[k + 1] - cuts[k];
+            const long long o0 = pre[u0], cnt = pre[cuts[k + 1]] - o0, r0 = rpre[u0], rcnt = rpre[cuts[k + 1]] - r0;
+            if (k > 0 && k < nregion) HIP_TRY(hipStreamWaitEvent(s, w.ev_meta, 0));
+            HIP_TRY(hipMemcpyAsync(w.in.d + o0, h_in + o0, (size_t)cnt * sizeof(short), hipMemcpyHostToDevice, s));
+            HIP_TRY(hipMemcpyAsync(w.mask.d + r0 * 64, h_mask + r0 * 64, (size_t)rcnt * 64 * sizeof(float), hipMemcpyHostToDevice, s));
+            if (sea_resynth64_batch(w.in.d + o0, w.out.d + o0, w.meta.d + u0, w.meta.d + n_utt + u0, w.mask.d + r0 * 64,
+                                    w.meta.d + 2 * n_utt + u0, (float *)((char *)w.d_inter + (size_t)r * region), nullptr, n,
+                                    binary, s))
+                return 1;
+            HIP_TRY(hipEventRecord(w.ev_kernel[k], s));
+            state[k] = kComputing;
+            progressed = true;
+        }
+        for (int k = 0; k < next; ++k) {
+            if (state[k] == kComputing && hipEventQuery(w.ev_kernel[k]) == hipSuccess) {
+                const long long o0 = pre[cuts[k]], cnt = pre[cuts[k + 1]] - o0;
+                hipStream_t s = w.stream[k % nregion];
+                HIP_TRY(hipMemcpyAsync(h_out + o0, w.out.d + o0, (size_t)cnt * sizeof(short), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipEventRecord(w.ev_done[k], s));
+                state[k] = kDownloading;
+                progressed = true;
+            }
+            if (state[k] == kDownloading && hipEventQuery(w.ev_done[k]) == hipSuccess) {
+                run_copies(cuts[k], cuts[k + 1], bp, &unpacked[k], &scope.all, small,
+                           [=](int j) { memcpy(out[ix[j]], h_out + prep[j], (size_t)lens[j] * sizeof(short)); });
+                state[k] = kUnpacking;
+                finished++;
+                progressed = true;
+            }
+        }
+        if (!progressed) {
+            if (next < nchunk) packed[next].wait_for(std::chrono::microseconds(30));
+            else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+    scope.all.wait();
+    scope.ok = true;
+    return 0;
+}
+
+} // extern "C"

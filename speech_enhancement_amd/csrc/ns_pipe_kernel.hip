@@ -179,7 +179,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
      * CU, and the step ends when the longest utterance does -- its waves (row 0) get s_setprio 3, row 1 -> 2, row 2 -> 1
      * (measured on the bench corpus, alternating A/B on one box: -2 %).  prio_row = 0 switches it off. */
     if (a.prio_row > 0) {
-        const int row = (int)blockIdx.x / a.prio_row;
+        const int row = a.prio_base + (int)blockIdx.x / a.prio_row;
         if (row == 0) __builtin_amdgcn_s_setprio(3);
         else if (row == 1) __builtin_amdgcn_s_setprio(2);
         else if (row == 2) __builtin_amdgcn_s_setprio(1);

@@ -25,7 +25,8 @@ struct NsBatchArgs {
     unsigned char *flags_out;  /* per output frame fo of utterance u, at [offsets[u]/8 + 10*fo]: bit 0 SpeechFoundVar,
                                 * 1 Spec, 2 Mel, 3 VADNS of the tick that produced the frame */
     int *onset_out;            /* per utterance: index of the first non-zero frame (number of frames if none) */
-    int prio_row;              /* > 0: workgroups [k * prio_row, (k+1) * prio_row) get issue priority 3 - k (four-wave form only) */
+    int prio_row;              /* > 0: workgroups [k * prio_row, (k+1) * prio_row) get issue priority 3 - k - prio_base (four-wave form only) */
+    int prio_base;             /* rows to skip: a later chunk of a batch launched in pieces (hostpipe.hip) starts below the first */
 };
 
 /* B independent streams, nframes frames of 80 floats each, state blobs of kNsStateFloats floats */

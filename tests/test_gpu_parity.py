@@ -280,6 +280,43 @@ def test_resynth_utterances_chunked_by_scratch_budget(oracle, monkeypatch):
         assert np.array_equal(got, w)
 
 
+def test_denoise_utterances_pipeline_any_chunking(oracle, monkeypatch):
+    """sea_denoise_utterances (the host-buffer entry the file driver uses, etsi/cpp/main.cpp:43-67 for a list) is a
+    copy / compute pipeline over chunks of the list (csrc/hostpipe.hip).  Whatever the chunk size and the number of
+    packing threads' tasks, every utterance must equal the oracle and the samples etsi_denoise never writes (the
+    trailing partial frame) must keep the caller's fill."""
+    import ctypes
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    _torch()
+    lib = sea.load()
+    assert lib.sea_host_threads() >= 1
+    rng = np.random.default_rng(11)
+    lens = [int(v) for v in rng.integers(0, 40000, 90)] + [0, 79, 80, 81, 24000, 24000, 24037]
+    utts = [corpus.synth_utterance(300 + i, L) for i, L in enumerate(lens)]
+    utts[5] = np.zeros(lens[5], np.int16)  # gate never opens
+    want = [oracle.etsi_denoise(x) for x in utts]
+
+    def run():
+        outs = [np.full(x.shape, 77, np.int16) for x in utts]
+        n = len(utts)
+        pin = (ctypes.c_void_p * n)(*[x.ctypes.data for x in utts])
+        po = (ctypes.c_void_p * n)(*[y.ctypes.data for y in outs])
+        pl = (ctypes.c_long * n)(*lens)
+        assert lib.sea_denoise_utterances(pin, po, pl, n) == 0, lib.sea_last_error()
+        return outs
+
+    for mb in ("1", "3", None):
+        if mb is None:
+            monkeypatch.delenv("SEA_HOST_CHUNK_MB")
+        else:
+            monkeypatch.setenv("SEA_HOST_CHUNK_MB", mb)
+        for u, (got, w, L) in enumerate(zip(run(), want, lens)):
+            full = L // 80 * 80
+            assert np.array_equal(got[:full], w[:full]), f"chunk {mb} MB: utterance {u} (L={L}) differs"
+            assert np.all(got[full:] == 77), f"chunk {mb} MB: utterance {u}: the trailing partial frame was written"
+
+
 def test_gammatone_filter_vs_oracle(oracle):
     import speech_enhancement_amd as sea
     _torch()

@@ -174,8 +174,33 @@ def main():
               flush=True)
         print(json.dumps({"metric": "NoiseSup frames/sec through the HOST-buffer entry point (PCIe inclusive)",
                           "value": batch.n_frames / wall, "unit": "frames/s", "ms_per_step": wall * 1e3,
-                          "config": {"workload": f"sea_denoise_utterances on {n} host utterances: pack, hipMalloc, "
-                                                 "H2D, one launch, D2H, unpack"}}), flush=True)
+                          "config": {"workload": f"sea_denoise_utterances on {n} host utterances: chunked pack | H2D | "
+                                                 f"launch | D2H | unpack pipeline, {lib.sea_host_threads()} packing threads"}}), flush=True)
+
+    if "hostrs" in what:
+        # resynth() through the host-buffer entry point (PCIe inclusive): int16 + mask rows in, int16 out
+        import ctypes
+        lib = sea.load()
+        host = batch.data.cpu().numpy()
+        ins = [np.ascontiguousarray(host[o:o + l]) for o, l in zip(batch.host_offsets, batch.host_lengths)]
+        outs = [np.zeros_like(x) for x in ins]
+        rng = np.random.default_rng(5)
+        masks = [rng.random(((x.size - 320) // 160 + 1, 64), dtype=np.float32) for x in ins]
+        n = len(ins)
+        pin = (ctypes.c_void_p * n)(*[x.ctypes.data for x in ins])
+        pm = (ctypes.c_void_p * n)(*[m.ctypes.data for m in masks])
+        pout = (ctypes.c_void_p * n)(*[x.ctypes.data for x in outs])
+        lens = (ctypes.c_long * n)(*[x.size for x in ins])
+        hops = int(sum(m.shape[0] for m in masks))
+        for binary in (0, 1):
+            assert lib.sea_resynth_utterances(pin, lens, pm, binary, pout, n) == 0, lib.sea_last_error()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                assert lib.sea_resynth_utterances(pin, lens, pm, binary, pout, n) == 0
+            wall = (time.perf_counter() - t0) / args.steps
+            print(json.dumps({"metric": f"resynth hop-frames/sec through the HOST-buffer entry point (PCIe inclusive), {'IBM' if binary else 'ratio mask'}",
+                              "value": hops / wall, "unit": "hop-frames/s", "ms_per_step": wall * 1e3,
+                              "config": {"workload": f"sea_resynth_utterances on {n} host utterances, {hops} mask rows"}}), flush=True)
 
     if "rfft" in what:
         n = 1 << 18
