@@ -70,6 +70,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the resynth / CompCeps / rfft256 lines")
     ap.add_argument("--also-steps", type=int, default=5)
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive host-buffer timings")
+    ap.add_argument("--no-configs4", action="store_true", help="skip the configs[4] shard line of the also-array")
     ap.add_argument("--cpu-utts", type=int, default=1024, help="utterances in the bounded CPU sample (1024 = ~10 core-seconds)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (the 1-GPU box share is 16)")
     ap.add_argument("--rehearse-cpu", action="store_true",
@@ -93,19 +95,40 @@ def spawn_ranks(n, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     # a rank that dies would leave the others waiting at the next barrier: when one exits non-zero, end the rest
-    # (exactly the processes started here)
+    # (exactly the processes started here).  The same when this launcher is interrupted or told to stop (SIGTERM
+    # from a harness timeout): no rank may be left behind holding a GPU at a gloo barrier.
+    import signal
+
+    def _stop(signum, frame):
+        raise KeyboardInterrupt(f"signal {signum}")
+    old = signal.signal(signal.SIGTERM, _stop)
     rc = 0
     live = list(procs)
-    while live:
-        time.sleep(0.2)
-        for p in list(live):
-            if p.poll() is None:
-                continue
-            live.remove(p)
-            rc = max(rc, abs(p.returncode))
-            if p.returncode != 0:
-                for q in live:
-                    q.terminate()
+    try:
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                if p.poll() is None:
+                    continue
+                live.remove(p)
+                rc = max(rc, abs(p.returncode))
+                if p.returncode != 0:
+                    for q in live:
+                        q.terminate()
+    except KeyboardInterrupt:
+        rc = max(rc, 130)
+    finally:
+        signal.signal(signal.SIGTERM, old)
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        deadline = time.time() + 10.0
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                q.kill()
+                q.wait()
     return rc
 
 
@@ -174,7 +197,7 @@ def corpus_shard_ids(corpus_utts, shards, rank):
     from speech_enhancement_amd import corpus
     from speech_enhancement_amd.shard import lpt_shards
     lengths = [corpus.utterance_length(u) for u in range(corpus_utts)]
-    return lpt_shards(lengths, shards)[rank % shards]
+    return lpt_shards(lengths, shards)[rank]
 
 
 def build_masks(batch, ids, device):
@@ -251,6 +274,23 @@ def _time_cpu(fn, utts, cores, passes):
     return dt, outs
 
 
+def cpu_model():
+    """The host CPU as /proc/cpuinfo names it, with the socket / core counts the box shows."""
+    model, phys, cores = "unknown", set(), 0
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys.add(line.split(":", 1)[1].strip())
+                elif line.startswith("processor"):
+                    cores += 1
+    except OSError:
+        pass
+    return f"{model} ({cores} logical CPUs on {max(1, len(phys))} socket(s); {len(os.sched_getaffinity(0))} usable by this process)"
+
+
 def cpu_baseline(batch, n_sample, threads):
     """kind "port": the oracle's C restatement, one utterance per thread over the host cores, on the
     first n_sample utterances of the shard.  Two builds, as BASELINE.md section 3 promised: the parity
@@ -269,21 +309,23 @@ def cpu_baseline(batch, n_sample, threads):
     dt_par, outs = _time_cpu(parity.etsi_denoise, utts, cores, passes)
     res = dict(unit="frames/s", cores=cores, kind="port", parity_build_value=passes * frames / dt_par,
                parity_build="gcc -O2 -ffp-contract=off (oracle/libsea_oracle.so)")
+    res["cpu_model"] = cpu_model()
     best = res["parity_build_value"]
+    tmp = tempfile.mkdtemp(prefix="sea_cpu_")
     try:  # the speed build must be made on the box it runs on (-march=native)
-        tmp = tempfile.mkdtemp(prefix="sea_cpu_")
         so = os.path.join(tmp, "libsea_oracle_native.so")
         subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-o", so,
                                os.path.join(ROOT, "oracle", "ns_oracle.c"), os.path.join(ROOT, "oracle", "resynth_oracle.c"),
                                "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         speed = O.Oracle(path=so)
-        shutil.rmtree(tmp, ignore_errors=True)  # the mapping stays valid after the file is gone
         dt_spd, _ = _time_cpu(speed.etsi_denoise, utts, cores, passes)
         res["speed_build_value"] = passes * frames / dt_spd
         res["speed_build"] = "gcc -O3 -march=native (FMA allowed: not bit-exact, timing only)"
         best = max(best, res["speed_build_value"])
     except Exception as e:  # no compiler on the box: say so, keep the parity build
         res["speed_build"] = f"unavailable ({type(e).__name__})"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)  # a loaded mapping stays valid after the file is gone
     if O.have_reference():
         dt_ref, _ = _time_cpu(O.Reference().etsi_denoise, utts, cores, passes)
         res["reference_value"] = passes * frames / dt_ref
@@ -384,18 +426,25 @@ def also_lines(batch, ids, device, steps):
     del f32, res
 
     # subbband() (gammatone + hair cell -> 64 int16 streams) and the IRM target computed from
-    # two such blocks (here the same block twice: the timing does not depend on the values)
+    # two DIFFERENT such blocks (clean = this corpus, noise = the same layout with the samples in reverse order: passing
+    # one block twice would let half of the reads hit in cache and overstate the rate)
     sub = torch.zeros(batch.total * 64, dtype=torch.int16, device=device)
+    sub2 = torch.zeros(batch.total * 64, dtype=torch.int16, device=device)
+    keep = batch.data
+    batch.data = torch.flip(keep, dims=[0]).contiguous()
+    sea.subband_batch(batch, out=sub2)
+    torch.cuda.synchronize()
+    batch.data = keep
     ker, wall = timed_steps(lambda: sea.subband_batch(batch, out=sub), max(2, steps // 2), 1)
     samples = int(np.sum(batch.host_lengths))
     line("subbband", f"SURVEY 8(f) #1: {batch.n_utt} utterances, 64-channel gammatone + Meddis hair cell to 64 int16 streams "
                      "(2 B read + 128 B written per sample)", samples, "samples/s", samples * 130, ker, wall,
          "sea::subband_kernel", "subband_bytes_per_launch")
-    ker, wall = timed_steps(lambda: sea.irm_target_batch(batch, sub, sub), max(2, steps // 2), 1)
-    line("IRM target", f"SURVEY 8(f) #2: make_single_IBM's ratio-mask target from two subband blocks, {hops} frames x 64 channels "
+    ker, wall = timed_steps(lambda: sea.irm_target_batch(batch, sub, sub2), max(2, steps // 2), 1)
+    line("IRM target", f"SURVEY 8(f) #2: make_single_IBM's ratio-mask target from two different subband blocks, {hops} frames x 64 channels "
                        "(2 x 128 B x 160 samples read + 256 B written per frame)", hops, "hop-frames/s",
          hops * (2 * 128 * 160 + 256), ker, wall, "sea::irm_target_kernel", "irm_bytes_per_launch")
-    del sub
+    del sub, sub2
 
     # the restored feature chain (NoiseSup with speech flags -> WaveProc -> CompCeps -> PostProc -> VAD),
     # three launches on device-resident buffers (the C ABI directly: engine.afe_features_batch also unpacks on the host)
@@ -430,19 +479,100 @@ def also_lines(batch, ids, device, steps):
          "sea::ns_denoise_pipe_fd_kernel + sea::afe_ceps_kernel + sea::afe_vad_kernel", "afe_bytes_per_launch")
     del outb, f32, flags, fcc, f15
 
-    # rfft256 on a streaming batch
-    nfr = 1 << 18
-    x = torch.randn(nfr, 256, device=device)
-    y = torch.empty_like(x)
+    # rfft256 on a streaming batch: 2^21 frames = 2 GiB in + 2 GiB out, 16 x the 256 MiB Infinity Cache (the HBM
+    # figure), and 2^18 frames = 256 MiB + 256 MiB, which partly lives in that cache (kept for comparison with round 2)
     lib = sea.load()
     st = torch.cuda.current_stream().cuda_stream
+    for nfr, name, key in ((1 << 21, "rfft256", "rfft256_2g_bytes_per_launch"), (1 << 18, "rfft256 (cache-sized)", "rfft256_bytes_per_launch")):
+        x = torch.randn(nfr, 256, device=device)
+        y = torch.empty_like(x)
 
-    def run_fft():
-        assert lib.sea_rfft256_batch(x.data_ptr(), y.data_ptr(), nfr, st) == 0
-    ker, wall = timed_steps(run_fft, steps, 1)
-    line("rfft256", f"{nfr} frames of 256 floats (etsi/cpp/rfft.c), out of place", nfr, "frames/s",
-         nfr * FFT_BYTES_PER_FRAME, ker, wall, "sea::rfft256_kernel", "rfft256_bytes_per_launch")
+        def run_fft():
+            assert lib.sea_rfft256_batch(x.data_ptr(), y.data_ptr(), nfr, st) == 0
+        ker, wall = timed_steps(run_fft, steps, 1)
+        line(name, f"{nfr} frames of 256 floats (etsi/cpp/rfft.c), out of place, {nfr * 2048 / 2**30:.2f} GiB moved per launch",
+             nfr, "frames/s", nfr * FFT_BYTES_PER_FRAME, ker, wall, "sea::rfft256_kernel", key)
+        del x, y
     return out
+
+
+def configs4_line(device, steps):
+    """BASELINE configs[4] on one GPU: LPT shard 0 of the 100 000-utterance corpus (12 500 utterances, ~10 M frames),
+    built on the device like the headline shard, one launch per step; the first and last 32 utterances of the shard
+    are compared with the CPU oracle exactly."""
+    import torch
+    import speech_enhancement_amd as sea
+    ids = corpus_shard_ids(100000, 8, 0)
+    batch = build_shard_ids(ids, device)
+    out = torch.zeros_like(batch.data)
+    ker, wall = timed_steps(lambda: sea.ns_denoise_batch(batch, out=out), steps, 1)
+    frames = batch.n_frames
+    alg = frames * NS_BYTES_PER_FRAME
+    from oracle import oracle as O
+    ora = O.Oracle()
+    pick = list(range(32)) + list(range(batch.n_utt - 32, batch.n_utt))
+    host_in, host_out = batch.data.cpu().numpy(), out.cpu().numpy()
+    bad = 0
+    with quiet_stderr():
+        for u in pick:
+            o, l = int(batch.host_offsets[u]), int(batch.host_lengths[u])
+            want = ora.etsi_denoise(np.ascontiguousarray(host_in[o:o + l]))
+            bad += int(not np.array_equal(host_out[o:o + l // 80 * 80], want[:l // 80 * 80]))
+    d = {"name": "NoiseSup, configs[4] shard", "workload": f"BASELINE configs[4]: shard 0 of 8 (LPT by samples) of the 100000-utterance "
+         f"corpus = {batch.n_utt} utterances, {frames} frames, one launch", "value": frames / wall, "unit": "frames/s",
+         "ms_per_step": wall * 1e3, "steps": steps, "rtf": wall / (frames * 80 / 16000.0),
+         "parity_check": f"{len(pick) - bad}/{len(pick)} sampled utterances bit-identical to the CPU oracle",
+         "roofline": {"bound": "hbm", "kernel": "sea::ns_denoise_pipe_big_kernel", "achieved": alg / ker / 1e9, "peak": HBM_PEAK_GBPS,
+                      "unit": "GB/s", "frac": alg / ker / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                      "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ker * 1e3}}
+    del batch, out
+    return d, bad
+
+
+def end_to_end(batch, steps):
+    """SURVEY 8(d) 'GPU timing': wall clock INCLUDING the PCIe copies, through the host-buffer drop-ins the
+    reference's callers use (etsi/cpp/main.cpp:43-67, aurora_speech_enhancement.cpp:25-80).  Never the headline."""
+    import ctypes
+    import speech_enhancement_amd as sea
+    lib = sea.load()
+    host = batch.data.cpu().numpy()
+    ins = [np.ascontiguousarray(host[o:o + l]) for o, l in zip(batch.host_offsets, batch.host_lengths)]
+    outs = [np.zeros_like(x) for x in ins]
+    n = len(ins)
+    pin = (ctypes.c_void_p * n)(*[x.ctypes.data for x in ins])
+    pout = (ctypes.c_void_p * n)(*[x.ctypes.data for x in outs])
+    lens = (ctypes.c_long * n)(*[x.size for x in ins])
+    with quiet_stderr():
+        assert lib.sea_denoise_utterances(pin, pout, lens, n) == 0, lib.sea_last_error()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            assert lib.sea_denoise_utterances(pin, pout, lens, n) == 0
+        wall = (time.perf_counter() - t0) / steps
+        # the reference's own calling pattern: one etsi_denoise(short*, short*, long) per utterance
+        k = min(n, 64)
+        fr1 = int(sum(x.size // 80 for x in ins[:k]))
+        lib.etsi_denoise(ins[0].ctypes.data, outs[0].ctypes.data, ins[0].size)
+        t1 = time.perf_counter()
+        for x, y in zip(ins[:k], outs[:k]):
+            assert lib.etsi_denoise(x.ctypes.data, y.ctypes.data, x.size) == 0
+        per_call = (time.perf_counter() - t1) / k
+        # the FEParamsX plug-in slot: one DoNoiseSup call per 80-sample frame of ONE stream
+        ns = sea.NoiseSup()
+        x = ins[0][:80 * 2000].astype(np.float32)
+        ns.DoNoiseSup(x[:80])
+        t2 = time.perf_counter()
+        for f in range(1, len(x) // 80):
+            ns.DoNoiseSup(x[80 * f:80 * f + 80])
+        per_frame = (time.perf_counter() - t2) / (len(x) // 80 - 1)
+    return {"note": "wall clock including pack, H2D, launch, D2H and unpack; never the headline value",
+            "denoise_utterances": {"value": batch.n_frames / wall, "unit": "frames/s", "ms_per_call": wall * 1e3,
+                                   "what": f"sea_denoise_utterances on the {n} utterances of this shard in host memory, "
+                                           f"{lib.sea_host_threads()} packing threads"},
+            "etsi_denoise_per_utterance": {"value": fr1 / (per_call * k), "unit": "frames/s", "ms_per_call": per_call * 1e3,
+                                           "what": f"{k} sequential etsi_denoise() calls, mean {fr1 / k:.0f} frames each"},
+            "ns_stream_push": {"value": per_frame * 1e6, "unit": "us per 80-sample frame",
+                               "what": "sea_ns_stream_push (the DoNoiseSup plug-in slot) on one stream, through ctypes; "
+                                       "the reference CPU needs ~12 us per frame (BASELINE.md section 2)"}}
 
 
 def rehearse_cpu(args, world, rank):
@@ -455,6 +585,8 @@ def rehearse_cpu(args, world, rank):
         init_gloo(rank, world)
     if os.environ.get("SEA_BENCH_REHEARSE_FAIL_RANK") == str(rank):   # test hook: a rank that dies after the rendezvous
         os._exit(7)
+    if args.corpus_utts > 0 and world > args.shards:
+        raise SystemExit(f"--corpus-utts: {world} ranks but only {args.shards} shards (each shard is run once; use --shards {world})")
     ids = (corpus_shard_ids(args.corpus_utts, args.shards, rank) if args.corpus_utts > 0
            else list(range(rank * args.utts, (rank + 1) * args.utts)))
     frames = int(sum(corpus.utterance_length(int(u)) // 80 for u in ids))
@@ -492,6 +624,8 @@ def run_rank(args):
 
     sea.load().sea_init(-1)
     if args.corpus_utts > 0:
+        if world > args.shards:
+            raise SystemExit(f"--corpus-utts: {world} ranks but only {args.shards} shards (each shard is run once; use --shards {world})")
         ids = corpus_shard_ids(args.corpus_utts, args.shards, rank)
         workload = (f"BASELINE configs[4]: {args.corpus_utts}-utterance synthetic corpus in {args.shards} LPT shards "
                     f"(balanced by samples), one shard per GPU; this run: {world} of {args.shards} shard(s), "
@@ -552,7 +686,7 @@ def run_rank(args):
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.corpus_utts > 0 else "weak",  # configs[4] is ONE fixed corpus cut into shards
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -579,6 +713,17 @@ def run_rank(args):
                 "avg_launch_ms": avg_kernel_s * 1e3,
             },
         }
+        # what actually bounds the kernel: vector-instruction issue.  Counters from the source-stamped profile passes,
+        # priced with tools/valu_probe.hip's issue costs (f32 2.1 clk per wave64 instruction, packed / f64 4.2,
+        # transcendental 8.4) on 1024 SIMDs at the 2.4 GHz peak engine clock.
+        insts, _ = (pmc_traffic("ns_valu_insts_per_launch") if (args.corpus_utts == 0 and args.utts == UTTS_PER_GPU) else (None, ""))
+        clk, _ = (pmc_traffic("ns_valu_issue_clk_per_launch") if insts else (None, ""))
+        if insts:
+            result["roofline"]["valu_insts_per_frame"] = insts / frames_per_step
+            if clk:
+                issue_s = clk / (1024 * 2.4e9)
+                result["roofline"]["valu_issue_ms"] = issue_s * 1e3
+                result["roofline"]["valu_issue_frac"] = issue_s / avg_kernel_s
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is reported at N=1 only
             base, outs = cpu_baseline(batch, args.cpu_utts, args.cpu_threads)
             result["cpu_baseline"] = base
@@ -591,7 +736,16 @@ def run_rank(args):
                 rc = 3
         if not args.no_also and world == 1:
             del out
+            if args.corpus_utts == 0 and not args.no_end_to_end:
+                result["end_to_end"] = end_to_end(batch, 5)
             result["also"] = also_lines(batch, ids, device, args.also_steps)
+            if args.corpus_utts == 0 and not args.no_configs4:
+                del batch
+                torch.cuda.empty_cache()
+                c4, bad4 = configs4_line(device, 3)
+                result["also"].insert(0, c4)
+                if bad4:
+                    rc = 3
     if world > 1:
         dist.barrier()
     if rank == 0:

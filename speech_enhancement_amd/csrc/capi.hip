@@ -561,9 +561,11 @@ int sea_gammatone_filter(const float *input, float *output, int chan, long sigLe
 
 /* ------------------------------------------------------------------------------------------- */
 struct sea_ns_stream {
-    float *state = nullptr;  /* kNsStateFloats */
-    float *io = nullptr;     /* 80 in + 80 out */
-    int *produced = nullptr;
+    float *state = nullptr;  /* kNsStateFloats, device */
+    float *h_io = nullptr;   /* pinned, device-visible: 80 in | 80 out | produced flag -- the kernel reads and writes it
+                              * over PCIe (324 B per push), so a push is ONE launch and ONE stream wait, no copy calls */
+    float *d_io = nullptr;   /* the device's address of h_io */
+    hipStream_t stream = nullptr;
     int fresh = 1;
 };
 
@@ -572,8 +574,10 @@ sea_ns_stream *sea_ns_stream_alloc(void)
     sea_ns_stream *s = new (std::nothrow) sea_ns_stream();
     if (!s) return nullptr;
     if (hipMalloc(&s->state, sea::kNsStateFloats * sizeof(float)) != hipSuccess ||
-        hipMalloc(&s->io, 160 * sizeof(float)) != hipSuccess || hipMalloc(&s->produced, sizeof(int)) != hipSuccess) {
-        fail("sea_ns_stream_alloc: hipMalloc failed");
+        hipHostMalloc((void **)&s->h_io, 164 * sizeof(float), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&s->d_io, s->h_io, 0) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
+        fail("sea_ns_stream_alloc: device allocation failed");
         sea_ns_stream_delete(s);
         return nullptr;
     }
@@ -594,25 +598,21 @@ int sea_ns_stream_push(sea_ns_stream *s, const float *in80, float *out80)
                   * a device fault must not look like success to the caller's shell, so the status is non-zero */
     }
     sea::NsStreamArgs a = {};
-    a.in = s->io;
-    a.out = s->io + 80;
-    a.produced = s->produced;
+    a.in = s->d_io;
+    a.out = s->d_io + 80;
+    a.produced = reinterpret_cast<int *>(s->d_io + 160);
     a.state = s->state;
     a.tables = c->ns;
     a.nframes = 1;
     a.reset = s->fresh;
-    int produced = 0;
-    bool ok = hipMemcpy(s->io, in80, 80 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
-    if (ok) {
-        hipLaunchKernelGGL(sea::ns_stream_kernel, dim3(1), dim3(64), 0, nullptr, a);
-        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
-             hipMemcpy(&produced, s->produced, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
-    }
-    if (ok && produced) ok = hipMemcpy(out80, s->io + 80, 80 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
-    if (!ok) {
+    memcpy(s->h_io, in80, 80 * sizeof(float));
+    hipLaunchKernelGGL(sea::ns_stream_kernel, dim3(1), dim3(64), 0, s->stream, a);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) {
         fprintf(stderr, "ERROR:   DoNoiseSup (MI355X): device failure\r\n");
         exit(1);
     }
+    const int produced = *reinterpret_cast<const volatile int *>(s->h_io + 160);
+    if (produced) memcpy(out80, s->h_io + 80, 80 * sizeof(float));
     s->fresh = 0;
     return produced;
 }
@@ -621,8 +621,8 @@ void sea_ns_stream_delete(sea_ns_stream *s)
 {
     if (!s) return;
     if (s->state) (void)hipFree(s->state);
-    if (s->io) (void)hipFree(s->io);
-    if (s->produced) (void)hipFree(s->produced);
+    if (s->h_io) (void)hipHostFree(s->h_io);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
 

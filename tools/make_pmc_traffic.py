@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/make_pmc_traffic.py <fetch_summary.txt> <write_summary.txt> <out.json> -- HBM bytes per launch of the
+"""tools/make_pmc_traffic.py <fetch_summary.txt> <write_summary.txt> <out.json> [<sq1_summary.txt> <mix1_summary.txt>] -- HBM bytes per launch of the
 bench kernels from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; summaries by tools/prof_summary.py),
 stamped with the sha of the kernel sources they were measured on (bench.py refuses a stale stamp).
 
@@ -25,6 +25,35 @@ def parse(path, counter):
     return out
 
 
+# issue cost of one wave64 vector instruction by class, in clocks of its SIMD (tools/valu_probe.hip,
+# profiles/r02_valu_probe.txt): f32 2.1, packed-f32 and f64 4.2, transcendental ~8.4
+COST = {"f32": 2.1, "f64": 4.2, "trans": 8.4}
+
+
+def parse_max(path, counter):
+    out = {}
+    for line in open(path):
+        m = re.match(r"sea::(\w+)\(.*\) " + counter + r": dispatches=(\d+) mean=([\d.]+) min=([\d.]+) max=([\d.]+)", line)
+        if m:
+            out[m.group(1)] = float(m.group(5))
+    return out
+
+
+def valu_issue(sq1, mix1):
+    """(vector instructions, priced issue clocks) per launch of the headline kernel from the SQ passes: every
+    instruction at the f32 cost, f64 ones at the f64 cost, transcendentals at theirs.  (Packed-f32 instructions have
+    no counter of their own and are priced as plain f32: the figure is a LOWER bound of the issue time.)"""
+    k = "ns_denoise_pipe_kernel"
+    total = parse(sq1, "SQ_INSTS_VALU").get(k)  # minimum over the dispatches = the plain launches, as for the traffic
+    if not total:
+        return None, None
+    f64 = sum(parse(mix1, c).get(k, 0.0) for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+    tr32 = parse(mix1, "SQ_INSTS_VALU_TRANS_F32").get(k, 0.0)
+    tr64 = parse(mix1, "SQ_INSTS_VALU_TRANS_F64").get(k, 0.0)
+    clk = (total - f64 - tr32 - tr64) * COST["f32"] + f64 * COST["f64"] + (tr32 + tr64) * COST["trans"]
+    return int(total), int(clk)
+
+
 def main():
     import bench
     fetch, write = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE")
@@ -39,6 +68,19 @@ def main():
     for k, name in keys.items():
         if k in fetch and k in write:
             j[name] = int(2 * fetch[k] * 1024 + write[k] * 1024)
+    # rfft256 runs at two sizes in the bench: the minimum over its dispatches is the cache-sized one, the maximum the 2 GiB one
+    fmax, wmax = parse_max(sys.argv[1], "FETCH_SIZE"), parse_max(sys.argv[2], "WRITE_SIZE")
+    if "rfft256_kernel" in fmax and "rfft256_kernel" in wmax:
+        j["rfft256_2g_bytes_per_launch"] = int(2 * fmax["rfft256_kernel"] * 1024 + wmax["rfft256_kernel"] * 1024)
+    # the feature chain is three launches
+    afe = ("ns_denoise_pipe_fd_kernel", "afe_ceps_kernel", "afe_vad_kernel")
+    if all(k in fetch and k in write for k in afe):
+        j["afe_bytes_per_launch"] = int(sum(2 * fetch[k] * 1024 + write[k] * 1024 for k in afe))
+    if len(sys.argv) > 5:  # SQ passes: <sq1 summary> <mix1 summary>
+        insts, clk = valu_issue(sys.argv[4], sys.argv[5])
+        if insts:
+            j["ns_valu_insts_per_launch"] = insts
+            j["ns_valu_issue_clk_per_launch"] = clk
     with open(sys.argv[3], "w") as f:
         json.dump(j, f, indent=1)
     print(json.dumps({k: v for k, v in j.items() if k.endswith("per_launch")}))
