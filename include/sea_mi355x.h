@@ -196,6 +196,21 @@ int sea_ns_state_floats(void);
 int sea_ns_streams_push_fd(const float *d_in, float *d_out, int *d_produced, unsigned char *d_flags,
                            int *d_frame_counter, float *d_state, int n_streams, int nframes, int reset, void *stream);
 
+/* The reference's batch plug-in symbols (function/20141106_speech_enhancement/aurora_etsi/NoiseSupExports.h:35-42;
+ * INSTANCE / PINSTANCE / int32s of the absent aurora/aurora_include.h = void*, void**, int), as adapters over
+ * sea_init / one state blob per thread instance / sea_ns_streams_push_fd (csrc/mapping.hip).  in_ins points to
+ * {float *inData; int dataNum}, out_ins to {float *outData; int *pSpeechFoundVar, *pSpeechFoundSpec, *pSpeechFoundMel,
+ * *pSpeechFoundVADNS, *pFrameCounter} (NoiseSupExports.h:14-27).  They run the etsi/ arithmetic on 80-sample frames
+ * (one call consumes dataNum / 80 frames), NOT the 16 k-native gammatone-window variant the reference builds behind
+ * these names; zero frames are skipped as func_Wiener skips them (aurora_etsi/NoiseSup.cpp:1160-1171); the FILE*
+ * argument is ignored.  global_init / thread_init return 1 on success, func_Wiener / func return 0. */
+int etsi_denoise_mapping_global_init(void **sm_glb_pins, void *sm_glb_res);
+int etsi_denoise_mapping_thread_init(void **sm_thd_pins, void *sm_glb_ins);
+int etsi_denoise_mapping_func_Wiener(void *sm_glb_ins, void *sm_thd_ins, void *in_ins, void *out_ins, void *fp_Wiener);
+int etsi_denoise_mapping_func(void *sm_glb_ins, void *sm_thd_ins, void *in_ins, void *out_ins);
+void etsi_denoise_mapping_thread_release(void **sm_thd_pins);
+void etsi_denoise_mapping_global_release(void **sm_glb_pins);
+
 /* ----------------------------------------------------------------------------------------------
  * device self-tests of the places where a kernel takes a cheaper route than the reference's
  * literal arithmetic (each proven or guarded, see csrc/sea_device.h, csrc/ns_core.h and DESIGN.md section 3)

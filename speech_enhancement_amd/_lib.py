@@ -53,6 +53,12 @@ PROTOTYPES = {
     "sea_ns_streams_push": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sea_ns_streams_push_fd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sea_ns_state_floats": (_i, []),
+    "etsi_denoise_mapping_global_init": (_i, [_vp, _vp]),
+    "etsi_denoise_mapping_thread_init": (_i, [_vp, _vp]),
+    "etsi_denoise_mapping_func_Wiener": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "etsi_denoise_mapping_func": (_i, [_vp, _vp, _vp, _vp]),
+    "etsi_denoise_mapping_thread_release": (None, [_vp]),
+    "etsi_denoise_mapping_global_release": (None, [_vp]),
     "sea_selftest_pi4": (_i, [_vp]),
     "sea_selftest_div": (_i, [_vp]),
     "sea_selftest_nsdiv": (_i, [_vp]),

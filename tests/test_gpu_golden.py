@@ -1,0 +1,135 @@
+"""GPU tests against the REFERENCE's own outputs, no oracle in the loop.
+
+tests/golden/*.npz were written by oracle/gen_golden.py from oracle/_ref/libetsi_ref.so -- the reference's
+etsi/cpp/*.c compiled where they lie -- on small seeded inputs; the files hold inputs and expected outputs only.
+Here the HIP path (through the C ABI) is fed those inputs and compared with the stored reference outputs directly:
+neither libsea_oracle.so nor oracle/_ref is loaded by this module.  Reference functions covered:
+
+  etsi_denoise            etsi/cpp/AdvFrontEnd.c:125-210       int16 out, bit-exact (tolerance stated: <= 2 LSB)
+  DoNoiseSup float stream etsi/cpp/NoiseSup.c:1061-1440        bit-exact (tolerance stated: 1e-4 relative)
+  rfft                    etsi/cpp/rfft.c:45-180               bit-exact
+  DoCompCeps              etsi/cpp/CompCeps.c:309-549          |delta| <= 1e-3 absolute
+  WaveProc..VAD chain     etsi/cpp/ParmInterface.c:274-311 (commented out there), WaveProc.c, PostProc.c, VAD.c
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = ("plain_1s", "leading_zeros", "ragged", "loud", "gap", "kat_head")
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: the -m gpu tests must run on the MI355X box")
+    return torch
+
+
+def test_golden_etsi_denoise_drop_in():
+    """int etsi_denoise(short*, short*, long), one call per golden utterance, against the reference's output
+    (written with fill -7777 beyond the last whole frame: those samples must keep the caller's fill here too)."""
+    import speech_enhancement_amd as sea
+    _torch()
+    g = np.load(os.path.join(GOLD, "ns_golden.npz"))
+    for name in NAMES:
+        x, want = g[f"{name}/in"], g[f"{name}/etsi_denoise"]
+        got = sea.etsi_denoise(x, fill=-7777)
+        assert np.array_equal(got, want), f"{name}: {np.count_nonzero(got != want)} of {len(x)} samples differ from the reference"
+
+
+def test_golden_noisesup_batch_int16_float_stream_and_cepstra():
+    """The batch entry points on the six golden utterances at once: int16 output, the float NoiseSup stream and
+    the cepstra computed from it, against the reference's ns_trace (NoiseSup driven explicitly, CompCeps through
+    BufInGetLast, oracle/ref_driver.c)."""
+    import speech_enhancement_amd as sea
+    torch = _torch()
+    g = np.load(os.path.join(GOLD, "ns_golden.npz"))
+    utts = [g[f"{n}/in"] for n in NAMES]
+    batch = sea.PackedBatch.from_arrays(utts)
+    out, f32, first = sea.ns_denoise_batch(batch, want_f32=True)
+    ceps, cum, n_ceps = sea.compceps_batch(batch, f32, first)
+    torch.cuda.synchronize()
+    got16 = batch.split(out, full_frames_only=True)
+    f32h, firsth, cepsh, nc = f32.cpu().numpy(), first.cpu().numpy(), ceps.cpu().numpy(), n_ceps.cpu().numpy()
+    worst = 0.0
+    for u, name in enumerate(NAMES):
+        full = len(utts[u]) // 80 * 80
+        want16 = g[f"{name}/etsi_denoise"][:full]
+        assert np.array_equal(got16[u], want16), f"{name}: int16 output differs from the reference"
+        den = g[f"{name}/den_f32"]                       # the reference's produced frames, back to back
+        assert firsth[u] >= 0 and (full // 80 - firsth[u]) * 80 == den.size, f"{name}: first output frame {firsth[u]}"
+        o = int(batch.host_offsets[u]) + 80 * int(firsth[u])
+        gotf = f32h[o:o + den.size]
+        assert np.array_equal(gotf.view(np.uint32), den.view(np.uint32)), \
+            f"{name}: {np.count_nonzero(gotf.view(np.uint32) != den.view(np.uint32))} of {den.size} floats of the NoiseSup stream differ"
+        wantc = g[f"{name}/ceps"]
+        assert int(nc[u]) == len(wantc), f"{name}: {int(nc[u])} cepstral frames, the reference has {len(wantc)}"
+        d = float(np.abs(cepsh[cum[u]:cum[u] + len(wantc)] - wantc).max())
+        worst = max(worst, d)
+        assert d <= 1e-3, f"{name}: cepstra off by {d}"
+    print("golden cepstra worst |delta| =", worst)
+
+
+def test_golden_rfft():
+    import speech_enhancement_amd as sea
+    torch = _torch()
+    g = np.load(os.path.join(GOLD, "rfft_golden.npz"))
+    got = sea.rfft_batch(torch.from_numpy(g["frames"]).cuda()).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), g["rfft"].view(np.uint32))
+    one = sea.rfft(g["frames"][5])                       # the drop-in symbol void rfft(float*, int, int)
+    assert np.array_equal(one.view(np.uint32), g["rfft"][5].view(np.uint32))
+
+
+def test_golden_compceps_frames():
+    import speech_enhancement_amd as sea
+    torch = _torch()
+    g = np.load(os.path.join(GOLD, "compceps_golden.npz"))
+    got = sea.compceps_frames(torch.from_numpy(g["data201"]).cuda()).cpu().numpy()
+    d = float(np.abs(got - g["coef"]).max())
+    print("golden DoCompCeps worst |delta| =", d)
+    assert d <= 1e-3
+    one = sea.DoCompCeps(g["data201"][3])                # the plug-in slot's host form
+    assert float(np.abs(one - g["coef"][3]).max()) <= 1e-3
+
+
+def test_golden_afe_feature_chain():
+    """Speech flags per NoiseSup output frame, features after CompCeps and after PostProc, and the emitted frames
+    with their VAD decisions, against what the reference's own DoWaveProc / DoCompCeps / DoPostProc / DoVADProc /
+    FlushAdvProcess produced on the golden utterances."""
+    import speech_enhancement_amd as sea
+    _torch()
+    gi = np.load(os.path.join(GOLD, "ns_golden.npz"))
+    g = np.load(os.path.join(GOLD, "afe_golden.npz"))
+    utts = [gi[f"{n}/in"] for n in NAMES]
+    batch = sea.PackedBatch.from_arrays(utts)
+    res = sea.afe_features_batch(batch, want_intermediates=True)
+    flags = res["flags"].cpu().numpy()
+    fcc, fpp = res["feat_cc"].cpu().numpy(), res["feat_pp"].cpu().numpy()
+    n_ceps, first = res["n_ceps"].cpu().numpy(), res["first_out"].cpu().numpy()
+    worst = 0.0
+    for u, name in enumerate(NAMES):
+        nfr = len(utts[u]) // 80
+        wf = g[f"{name}/flags"]
+        assert wf.shape[0] == nfr
+        f0 = int(first[u])
+        got = flags[batch.host_offsets[u] // 8 + 10 * np.arange(f0, nfr)]
+        want = wf[f0:nfr, :4] @ np.array([1, 2, 4, 8])
+        assert np.array_equal(got, want), f"{name}: speech flags differ at frames {np.nonzero(got != want)[0][:5] + f0}"
+        wcc, wpp, w15 = g[f"{name}/feat_cc"], g[f"{name}/feat_pp"], g[f"{name}/vad_out"]
+        assert int(n_ceps[u]) == len(wcc), f"{name}: cepstral frame count"
+        c0 = res["ceps_cum"][u]
+        for what, gg, ww in (("feat_cc", fcc, wcc), ("feat_pp", fpp, wpp)):
+            d = float(np.abs(gg[c0:c0 + len(ww)] - ww).max()) if len(ww) else 0.0
+            worst = max(worst, d)
+            assert d <= 1e-3, f"{name} {what}: off by {d}"
+        got15 = res["feats"][u]
+        assert got15.shape == w15.shape, f"{name}: {got15.shape} emitted frames, the reference has {w15.shape}"
+        assert np.array_equal(got15[:, 14], w15[:, 14]), f"{name}: VAD decisions differ"
+        d = float(np.abs(got15[:, :14] - w15[:, :14]).max())
+        worst = max(worst, d)
+        assert d <= 1e-3, f"{name}: emitted features off by {d}"
+    print("golden AFE chain worst |delta| =", worst)

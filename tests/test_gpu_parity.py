@@ -778,6 +778,63 @@ def test_ns_stream_plugin_flags_vs_oracle(oracle):
         assert np.array_equal(out[b, 4:].reshape(-1).view(np.uint32), ns["den_f32"].view(np.uint32))
 
 
+def test_etsi_denoise_mapping_symbols(oracle):
+    """The reference's batch plug-in symbols (function/20141106_speech_enhancement/aurora_etsi/NoiseSupExports.h:35-42),
+    exported as adapters with 8 kHz-mode (etsi/) semantics, through the C ABI: global / thread instances, two
+    func_Wiener calls on one thread instance (the state crosses the calls), zero frames skipped without touching
+    their output entries (aurora_etsi/NoiseSup.cpp:1160-1171), a second thread instance starting afresh."""
+    import ctypes
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    _torch()
+    lib = sea.load()
+
+    class In(ctypes.Structure):
+        _fields_ = [("inData", ctypes.c_void_p), ("dataNum", ctypes.c_int)]
+
+    class Out(ctypes.Structure):
+        _fields_ = [("outData", ctypes.c_void_p), ("pSpeechFoundVar", ctypes.c_void_p), ("pSpeechFoundSpec", ctypes.c_void_p),
+                    ("pSpeechFoundMel", ctypes.c_void_p), ("pSpeechFoundVADNS", ctypes.c_void_p), ("pFrameCounter", ctypes.c_void_p)]
+
+    x = corpus.synth_utterance(5, 80 * 150)           # utterance 5: its first 400 samples (5 frames) are zero
+    x[80 * 60:80 * 63] = 0                            # and three zero frames in the middle: skipped, no state change
+    nfr = len(x) // 80
+    tr = oracle.afe_trace(np.concatenate([x[:80 * 60], x[80 * 63:]]))   # what the processed frames must give
+    ns = oracle.ns_trace(np.concatenate([x[:80 * 60], x[80 * 63:]]), want_state=False)
+    keep = np.array([n for n in range(nfr) if np.any(x[80 * n:80 * n + 80])])
+    assert len(keep) == nfr - 5 - 3
+    glb, thd = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.etsi_denoise_mapping_global_init(ctypes.byref(glb), None) == 1
+    for attempt in range(2):                          # the second pass: a fresh thread instance gives the same again
+        assert lib.etsi_denoise_mapping_thread_init(ctypes.byref(thd), glb) == 1
+        xf = x.astype(np.float32)
+        out = np.full(nfr * 80, -7.0, np.float32)
+        arrs = [np.full(nfr, -7, np.int32) for _ in range(5)]
+        for a, b, fn in ((0, 37, lib.etsi_denoise_mapping_func_Wiener), (37, nfr, lib.etsi_denoise_mapping_func)):
+            i = In(xf[80 * a:].ctypes.data, 80 * (b - a) + 13)          # 13 samples beyond the last whole frame: ignored
+            o = Out(out[80 * a:].ctypes.data, *[v[a:].ctypes.data for v in arrs])
+            args = (glb, thd, ctypes.byref(i), ctypes.byref(o)) + ((None,) if fn is lib.etsi_denoise_mapping_func_Wiener else ())
+            assert fn(*args) == 0, lib.sea_last_error()
+        lib.etsi_denoise_mapping_thread_release(ctypes.byref(thd))
+        assert not thd.value
+        var, spec, mel, vadns, cnt = arrs
+        skipped = np.setdiff1d(np.arange(nfr), keep)
+        assert np.all(out.reshape(nfr, 80)[skipped] == -7.0) and all(np.all(v[skipped] == -7) for v in arrs)
+        # processed frame k of the compacted utterance = input frame keep[k]; the reference's trace counts from its first
+        # non-zero frame too (DoAdvProcess gates the same way), 5 leading zero frames there as here
+        tflags = tr["flags"][5:]                                           # per processed frame
+        ran0 = tflags[:, 4] >= 1
+        assert np.array_equal(cnt[keep][ran0], tflags[ran0, 4])
+        assert np.all(cnt[keep][~ran0] == -7)
+        for col, v in enumerate((var, spec, mel, vadns)):
+            assert np.array_equal(v[keep][ran0], tflags[ran0, col]), f"flag {col}"
+        produced = out.reshape(nfr, 80)[keep][4:]                           # outputs from the 5th processed frame on
+        assert np.all(out.reshape(nfr, 80)[keep][:4] == -7.0)
+        assert np.array_equal(produced.reshape(-1).view(np.uint32), ns["den_f32"].view(np.uint32))
+    lib.etsi_denoise_mapping_global_release(ctypes.byref(glb))
+    assert not glb.value
+
+
 def test_ns_large_batch_kernel_form(oracle):
     """More than four utterances per CU selects the lower-register form of the pipelined kernel
     (transform address tables in LDS): same results."""
