@@ -141,6 +141,11 @@ long long sea_resynth_scratch_bytes(long long total_padded_samples, int n_utt);
  * do not depend on the cut. */
 int sea_denoise_utterances(const short *const *in, short *const *out, const long *lengths, int n_utt);
 int sea_host_threads(void); /* size of that pool */
+/* NoiseSup + CompCeps from host buffers, the chain ParmInterface.c:275-293 ran before its author commented it out
+ * (SURVEY 8(d) Config 1: a 4-s utterance gives 800 NoiseSup frames, 796 outputs, 794 cepstral frames): out as above;
+ * ceps[u] receives n_ceps[u] rows of 14 floats (c1..c12, c0, logE), capacity max(lengths[u]/80 - 6, 0) rows. */
+int sea_denoise_ceps_utterances(const short *const *in, short *const *out, float *const *ceps, int *n_ceps,
+                                const long *lengths, int n_utt);
 
 /* DoCompCeps(Data, Coef, This): Data[-1] must be valid (host pointers) */
 int sea_compceps_frame(const float *Data, float *Coef14);

@@ -496,6 +496,72 @@ int sea_denoise_utterances(const short *const *in, short *const *out, const long
 }
 
 /* ---------------------------------------------------------------------------------------------------- */
+/* NoiseSup + CompCeps from host buffers: the explicit chain SURVEY 8(c) describes for the reference (DoNoiseSup into
+ * the denoised-sample shift register, DoCompCeps on its last 201 samples from the third output on,
+ * etsi/cpp/ParmInterface.c:275-293).  ceps[u] receives n_ceps[u] rows of 14 floats (c1..c12, c0, logE); its capacity
+ * must be max(lengths[u]/80 - 6, 0) rows.  One launch each, no chunking (the feature path of the file driver). */
+int sea_denoise_ceps_utterances(const short *const *in, short *const *out, float *const *ceps, int *n_ceps,
+                                const long *lengths, int n_utt)
+{
+    if (n_utt <= 0) return 0;
+    DeviceCtx *dc;
+    if (ctx(&dc)) return 1;
+    std::vector<long long> pre(n_utt + 1, 0), cum(n_utt + 1, 0);
+    for (int u = 0; u < n_utt; ++u) {
+        if (lengths[u] < 0) return fail("negative length for utterance %d", u);
+        pre[u + 1] = pre[u] + align8(lengths[u]);
+        cum[u + 1] = cum[u] + std::max<long long>(lengths[u] / 80 - 6, 0);
+    }
+    const long long total = pre[n_utt], total_ceps = cum[n_utt];
+    for (int u = 0; u < n_utt; ++u) n_ceps[u] = 0;
+    if (total == 0) return 0;
+    PipeWs &w = t_ws;
+    HIP_TRY(w.bind());
+    HIP_TRY(w.in.ensure((size_t)total));
+    HIP_TRY(w.out.ensure((size_t)total));
+    HIP_TRY(w.meta.ensure(3 * (size_t)n_utt + 1));
+    long long *offs = w.meta.h, *lens = w.meta.h + n_utt, *ccum = w.meta.h + 2 * n_utt;
+    std::vector<int> order(n_utt);
+    for (int u = 0; u < n_utt; ++u) {
+        offs[u] = pre[u];
+        lens[u] = lengths[u];
+        memcpy(w.in.h + pre[u], in[u], (size_t)lengths[u] * sizeof(short));
+        const long long pad = align8(lengths[u]) - lengths[u];
+        if (pad) memset(w.in.h + pre[u] + lengths[u], 0, (size_t)pad * sizeof(short));
+    }
+    for (int u = 0; u <= n_utt; ++u) ccum[u] = cum[u];
+    launch_order(lens, n_utt, dc->n_cu, order.data());
+    DevBuf<float> d_f32, d_ceps;
+    DevBuf<int> d_first, d_nceps, d_order;
+    HIP_TRY(d_f32.alloc((size_t)total));
+    HIP_TRY(d_ceps.alloc((size_t)std::max<long long>(total_ceps, 1) * 14));
+    HIP_TRY(d_first.alloc(n_utt));
+    HIP_TRY(d_nceps.alloc(n_utt));
+    HIP_TRY(d_order.alloc(n_utt));
+    hipStream_t s = w.stream[0];
+    HIP_TRY(hipMemcpyAsync(w.in.d, w.in.h, (size_t)total * sizeof(short), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(w.meta.d, w.meta.h, (3 * (size_t)n_utt + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_order.p, order.data(), (size_t)n_utt * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(d_nceps.p, 0, (size_t)n_utt * sizeof(int), s));
+    if (sea_ns_denoise_batch(w.in.d, w.out.d, d_f32.p, w.meta.d, w.meta.d + n_utt, n_utt > 1 ? d_order.p : nullptr, d_first.p,
+                             n_utt, s))
+        return 1;
+    if (total_ceps > 0 && sea_compceps_batch(d_f32.p, w.meta.d, w.meta.d + n_utt, d_first.p, w.meta.d + 2 * n_utt, total_ceps,
+                                             d_ceps.p, d_nceps.p, n_utt, s))
+        return 1;
+    std::vector<float> h_ceps((size_t)std::max<long long>(total_ceps, 1) * 14);
+    HIP_TRY(hipMemcpyAsync(w.out.h, w.out.d, (size_t)total * sizeof(short), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h_ceps.data(), d_ceps.p, h_ceps.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(n_ceps, d_nceps.p, (size_t)n_utt * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int u = 0; u < n_utt; ++u) {
+        memcpy(out[u], w.out.h + pre[u], (size_t)(lengths[u] / 80 * 80) * sizeof(short));
+        if (n_ceps[u] > 0) memcpy(ceps[u], h_ceps.data() + (size_t)cum[u] * 14, (size_t)n_ceps[u] * 14 * sizeof(float));
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------- */
 /* The [time][64] float intermediate costs 256 B of HBM per sample (~16 MB per 4-s utterance).  The chunks of the
  * pipeline run on kStreams streams, each with a scratch region of its own, sized so that all regions together fit
  * in 60 % of the HBM that is free right now (SEA_RESYNTH_SCRATCH_MB overrides the budget); a chunk is at most what

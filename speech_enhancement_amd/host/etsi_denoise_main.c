@@ -13,12 +13,19 @@
  * libsea_mi355x.so; each utterance's result equals etsi_denoise() on it alone.  The reference
  * leaves the trailing len%80 samples of its new[]'ed buffer uninitialised; here they are 0.
  *
- * Several GPUs: the reference's only parallel harness is a pool of threads that pull file indices from a
- * shared counter (function/20141106_speech_enhancement/aurora_speech_enhancement/aurora_speech_enhancement.cpp:
- * 111-121, 311-327).  Same shape here, one step coarser: one host thread per device (sea_device_count(), or
- * SEA_DEVICES=n; more threads than devices share them round robin) pulls CHUNKS of the list from a shared
- * counter and runs each on its own device -- no data crosses between devices.
+ * Shape: the reference's only parallel harness is a pool of threads that pull file indices from a shared counter
+ * (function/20141106_speech_enhancement/aurora_speech_enhancement/aurora_speech_enhancement.cpp:111-121, 311-327).
+ * Here, one step coarser and with the file I/O taken off the GPU's critical path:
+ *   reader threads   pull CHUNKS of the list from a shared counter, read their WAVs          -> queue
+ *   device threads   one per device (sea_device_count(), or SEA_DEVICES=n; more threads than devices share them
+ *                    round robin): sea_init(dev), then one sea_denoise_utterances per chunk  -> queue
+ *   writer threads   write the chunk's WAVs, free it
+ * so chunk k+1 is being read and chunk k-1 written while chunk k is on a GPU; no data crosses between devices.
+ *
  *   --dry-run   parse cfg/list/WAVs and report, no GPU work, nothing written
+ *   --ceps      also write <id>_e_resynth.ceps next to each output WAV: the cepstra DoCompCeps gives on the denoised
+ *               stream (etsi/cpp/ParmInterface.c:275-293, commented out in the reference): int32 rows, int32 14, then
+ *               rows x 14 float32 (c1..c12, c0, logE)
  */
 #include <pthread.h>
 #include <stdio.h>
@@ -30,14 +37,16 @@
 
 #define CHUNK_MAX 4096
 #define CHUNK_MIN 64
+#define MAX_THREADS 64
 
 typedef struct {
     const sea_cfg *opts;
     char **ids;
-    int n_ids, chunk, dry, n_dev;
+    int n_ids, chunk, dry, n_dev, ceps;
     FILE *Log;
-    pthread_mutex_t mu; /* the shared chunk counter, stdout / Log lines */
+    pthread_mutex_t mu; /* the shared chunk counter, stdout / Log lines, rc */
     int next, rc;
+    sea_queue to_device, to_writer;
 } job_t;
 
 typedef struct {
@@ -45,21 +54,21 @@ typedef struct {
     int index;
 } worker_t;
 
-static void *worker(void *arg)
+static void set_rc(job_t *J, int rc)
 {
-    worker_t *w = (worker_t *)arg;
-    job_t *J = w->job;
+    pthread_mutex_lock(&J->mu);
+    if (!J->rc) J->rc = rc;
+    pthread_mutex_unlock(&J->mu);
+}
+
+static void *reader(void *arg)
+{
+    job_t *J = ((worker_t *)arg)->job;
     const sea_cfg *opts = J->opts;
     char path[4 * SEA_FILE_LEN];
-    if (!J->dry && sea_init(J->n_dev > 0 ? w->index % J->n_dev : -1)) {
-        fprintf(stderr, "ERROR:   %s\n", sea_last_error());
-        pthread_mutex_lock(&J->mu);
-        J->rc = 1;
-        pthread_mutex_unlock(&J->mu);
-        return NULL;
-    }
     for (;;) {
-        int first, rc = 0;
+        int first, n, u;
+        sea_chunk *c;
         pthread_mutex_lock(&J->mu);
         first = J->next;
         if (J->rc || first >= J->n_ids) {
@@ -68,55 +77,95 @@ static void *worker(void *arg)
         }
         J->next = first + J->chunk;
         pthread_mutex_unlock(&J->mu);
-        {
-        char **ids = J->ids;
-        FILE *Log = J->Log;
-        const int n_ids = J->n_ids, dry = J->dry, CHUNK = J->chunk;
-        int n = (n_ids - first < CHUNK) ? n_ids - first : CHUNK, u;
-        short **in = (short **)calloc(n, sizeof(short *)), **out = (short **)calloc(n, sizeof(short *));
-        long *len = (long *)calloc(n, sizeof(long));
+        n = (J->n_ids - first < J->chunk) ? J->n_ids - first : J->chunk;
+        c = sea_chunk_new(first, n, 0, J->ceps);
+        if (!c) {
+            set_rc(J, 1);
+            break;
+        }
         for (u = 0; u < n; u++) {
             int fs = 0;
-            const char *id = ids[first + u];
+            const char *id = J->ids[first + u];
             snprintf(path, sizeof path, "%s%s%s_noisy.wav", opts->outputDictionary, opts->save_noisy_dir, id);
             pthread_mutex_lock(&J->mu);
             printf("%s\n", id);
-            if (Log) fprintf(Log, "%s\n ", id);
+            if (J->Log) fprintf(J->Log, "%s\n ", id);
             printf("%s %d\n", path, first + u);
             pthread_mutex_unlock(&J->mu);
-            if (sea_wav_read(path, &in[u], &len[u], &fs)) {
+            if (sea_wav_read(path, &c->in[u], &c->len[u], &fs)) {
                 fprintf(stderr, "ERROR:   cannot read %s\n", path);
-                rc = 3;
-                len[u] = 0;
+                c->rc = 3;
+                c->len[u] = 0;
                 continue;
             }
-            out[u] = (short *)calloc(len[u] ? len[u] : 1, sizeof(short));
-            if (dry) printf("  %ld samples, %d Hz\n", len[u], fs);
+            c->out[u] = (short *)calloc(c->len[u] ? c->len[u] : 1, sizeof(short));
+            if (J->ceps) {
+                const long cap = c->len[u] / 80 - 6;
+                c->ceps[u] = (float *)calloc((size_t)(cap > 0 ? cap : 1) * 14, sizeof(float));
+            }
+            if (J->dry) printf("  %ld samples, %d Hz\n", c->len[u], fs);
         }
-        if (!dry && !rc) {
-            if (sea_denoise_utterances((const short *const *)in, out, len, n)) {
+        if (c->rc) set_rc(J, c->rc);
+        sea_queue_put(&J->to_device, c);
+    }
+    sea_queue_producer_done(&J->to_device);
+    return NULL;
+}
+
+static void *device_thread(void *arg)
+{
+    worker_t *w = (worker_t *)arg;
+    job_t *J = w->job;
+    sea_chunk *c;
+    int ok = 1;
+    if (!J->dry && sea_init(J->n_dev > 0 ? w->index % J->n_dev : -1)) {
+        fprintf(stderr, "ERROR:   %s\n", sea_last_error());
+        set_rc(J, 1);
+        ok = 0;
+    }
+    while ((c = sea_queue_get(&J->to_device)) != NULL) {
+        if (ok && !J->dry && !c->rc) {
+            const int bad = J->ceps ? sea_denoise_ceps_utterances((const short *const *)c->in, c->out, c->ceps, c->n_ceps, c->len, c->n)
+                                    : sea_denoise_utterances((const short *const *)c->in, c->out, c->len, c->n);
+            if (bad) {
                 fprintf(stderr, "ERROR:   %s\n", sea_last_error());
-                rc = 1;
+                c->rc = 1;
+                set_rc(J, 1);
             }
-            for (u = 0; u < n && !rc; u++) {
-                snprintf(path, sizeof path, "%s%s%s_e_resynth.wav", opts->outputDictionary, opts->save_resynth_e_dir,
-                         ids[first + u]);
-                if (sea_wav_write(path, out[u], len[u], 16000)) rc = 4;
+        } else if (!ok)
+            c->rc = 1;
+        sea_queue_put(&J->to_writer, c);
+    }
+    sea_queue_producer_done(&J->to_writer);
+    return NULL;
+}
+
+static void *writer(void *arg)
+{
+    job_t *J = ((worker_t *)arg)->job;
+    const sea_cfg *opts = J->opts;
+    char path[4 * SEA_FILE_LEN];
+    sea_chunk *c;
+    while ((c = sea_queue_get(&J->to_writer)) != NULL) {
+        int u, rc = c->rc;
+        for (u = 0; u < c->n && !rc && !J->dry; u++) {
+            snprintf(path, sizeof path, "%s%s%s_e_resynth.wav", opts->outputDictionary, opts->save_resynth_e_dir,
+                     J->ids[c->first + u]);
+            if (sea_wav_write(path, c->out[u], c->len[u], 16000)) rc = 4;
+            if (!rc && J->ceps) {
+                FILE *f;
+                const int hdr[2] = {c->n_ceps[u], 14};
+                snprintf(path, sizeof path, "%s%s%s_e_resynth.ceps", opts->outputDictionary, opts->save_resynth_e_dir,
+                         J->ids[c->first + u]);
+                f = fopen(path, "wb");
+                if (!f || fwrite(hdr, sizeof hdr, 1, f) != 1 ||
+                    (c->n_ceps[u] > 0 && fwrite(c->ceps[u], 14 * sizeof(float), (size_t)c->n_ceps[u], f) != (size_t)c->n_ceps[u]))
+                    rc = 4;
+                if (f) fclose(f);
             }
         }
-        for (u = 0; u < n; u++) {
-            free(in[u]);
-            free(out[u]);
-        }
-        free(in);
-        free(out);
-        free(len);
-        }
-        if (rc) {
-            pthread_mutex_lock(&J->mu);
-            if (!J->rc) J->rc = rc;
-            pthread_mutex_unlock(&J->mu);
-        }
+        if (rc) set_rc(J, rc);
+        sea_chunk_free(c);
     }
     return NULL;
 }
@@ -125,52 +174,82 @@ int main(int argc, char *argv[])
 {
     sea_cfg opts;
     char path[4 * SEA_FILE_LEN], **ids = NULL;
-    int n_ids, dry = 0, n_dev = 0, n_thr, k;
+    int n_ids, n_dev = 0, n_thr, n_read, n_write, n_chunks, k, a;
     job_t J;
-    pthread_t thr[64];
-    worker_t wk[64];
+    pthread_t rd[MAX_THREADS], dv[MAX_THREADS], wr[MAX_THREADS];
+    worker_t wk[MAX_THREADS];
     const char *e;
     if (argc < 2) {
-        fprintf(stderr, "usage: %s <cfg> [--dry-run]\n", argv[0]);
+        fprintf(stderr, "usage: %s <cfg> [--dry-run] [--ceps]\n", argv[0]);
         return 2;
     }
-    dry = argc > 2 && !strcmp(argv[2], "--dry-run");
+    memset(&J, 0, sizeof J);
+    for (a = 2; a < argc; a++) {
+        if (!strcmp(argv[a], "--dry-run")) J.dry = 1;
+        else if (!strcmp(argv[a], "--ceps")) J.ceps = 1;
+        else {
+            fprintf(stderr, "usage: %s <cfg> [--dry-run] [--ceps]\n", argv[0]);
+            return 2;
+        }
+    }
     if (sea_read_cfg(argv[1], 1, &opts)) return 2;
     n_ids = sea_read_list(opts.purewavlist, &ids);
     if (n_ids < 0) {
         fprintf(stderr, "Open %s file error!\n", opts.purewavlist);
         return 2;
     }
-    if (!dry) n_dev = sea_device_count();
+    if (!J.dry) n_dev = sea_device_count();
     n_thr = n_dev > 0 ? n_dev : 1;
     if ((e = getenv("SEA_DEVICES")) && atoi(e) > 0) n_thr = atoi(e);
-    if (n_thr > 64) n_thr = 64;
-    memset(&J, 0, sizeof J);
+    if (n_thr > MAX_THREADS) n_thr = MAX_THREADS;
     J.opts = &opts;
     J.ids = ids;
     J.n_ids = n_ids;
-    J.dry = dry;
     J.n_dev = n_dev;
-    /* chunks: about four per thread so that the shared counter balances unequal chunks, within [64, 4096] utterances */
+    /* chunks: about four per device thread so that the shared counter balances unequal chunks, within [64, 4096] utterances */
     J.chunk = (n_ids + 4 * n_thr - 1) / (4 * n_thr);
     if (J.chunk < CHUNK_MIN) J.chunk = CHUNK_MIN;
     if (J.chunk > CHUNK_MAX) J.chunk = CHUNK_MAX;
-    snprintf(path, sizeof path, "%s%s", opts.outputDictionary, opts.Log);
-    J.Log = dry ? NULL : fopen(path, "a+");
-    pthread_mutex_init(&J.mu, NULL);
-    if (n_thr > (n_ids + J.chunk - 1) / J.chunk) n_thr = (n_ids + J.chunk - 1) / J.chunk;
+    n_chunks = (n_ids + J.chunk - 1) / J.chunk;
+    if (n_thr > n_chunks) n_thr = n_chunks;
     if (n_thr < 1) n_thr = 1;
-    for (k = 0; k < n_thr; k++) {
+    /* file I/O: a few threads each side keep one device busy (a chunk is read in ~ms per file, on the GPU in ~7 ms per
+     * thousand files); SEA_IO_THREADS overrides */
+    n_read = 2 * n_thr;
+    if ((e = getenv("SEA_IO_THREADS")) && atoi(e) > 0) n_read = atoi(e);
+    if (n_read > n_chunks) n_read = n_chunks;
+    if (n_read > MAX_THREADS) n_read = MAX_THREADS;
+    if (n_read < 1) n_read = 1;
+    n_write = n_read;
+    snprintf(path, sizeof path, "%s%s", opts.outputDictionary, opts.Log);
+    J.Log = J.dry ? NULL : fopen(path, "a+");
+    pthread_mutex_init(&J.mu, NULL);
+    sea_queue_init(&J.to_device, 2 * n_thr, n_read);
+    sea_queue_init(&J.to_writer, 2 * n_thr, n_thr);
+    for (k = 0; k < MAX_THREADS; k++) {
         wk[k].job = &J;
         wk[k].index = k;
-        if (k > 0 && pthread_create(&thr[k], NULL, worker, &wk[k])) {
-            fprintf(stderr, "ERROR:   cannot start worker thread %d\n", k);
-            n_thr = k;
-            break;
-        }
     }
-    worker(&wk[0]);
-    for (k = 1; k < n_thr; k++) pthread_join(thr[k], NULL);
+    for (k = 0; k < n_write; k++)
+        if (pthread_create(&wr[k], NULL, writer, &wk[k])) {
+            fprintf(stderr, "ERROR:   cannot start writer thread %d\n", k);
+            return 1;
+        }
+    for (k = 0; k < n_thr; k++)
+        if (pthread_create(&dv[k], NULL, device_thread, &wk[k])) {
+            fprintf(stderr, "ERROR:   cannot start device thread %d\n", k);
+            return 1;
+        }
+    for (k = 0; k < n_read; k++)
+        if (pthread_create(&rd[k], NULL, reader, &wk[k])) {
+            fprintf(stderr, "ERROR:   cannot start reader thread %d\n", k);
+            return 1;
+        }
+    for (k = 0; k < n_read; k++) pthread_join(rd[k], NULL);
+    for (k = 0; k < n_thr; k++) pthread_join(dv[k], NULL);
+    for (k = 0; k < n_write; k++) pthread_join(wr[k], NULL);
+    sea_queue_destroy(&J.to_device);
+    sea_queue_destroy(&J.to_writer);
     pthread_mutex_destroy(&J.mu);
     if (J.Log) fclose(J.Log);
     sea_free_list(ids, n_ids);

@@ -200,3 +200,95 @@ long sea_mask_text_read(FILE *fp, char *id_out, float *mask64, long max_rows)
     }
     return row;
 }
+
+/* ---- chunk + bounded queue (see sea_host.h) ---- */
+sea_chunk *sea_chunk_new(int first, int n, int with_mask, int with_ceps)
+{
+    sea_chunk *c = (sea_chunk *)calloc(1, sizeof *c);
+    if (!c) return NULL;
+    c->first = first;
+    c->n = n;
+    c->in = (short **)calloc(n > 0 ? n : 1, sizeof *c->in);
+    c->out = (short **)calloc(n > 0 ? n : 1, sizeof *c->out);
+    c->len = (long *)calloc(n > 0 ? n : 1, sizeof *c->len);
+    c->used = (int *)calloc(n > 0 ? n : 1, sizeof *c->used);
+    if (with_mask) c->mask = (float **)calloc(n > 0 ? n : 1, sizeof *c->mask);
+    if (with_ceps) {
+        c->ceps = (float **)calloc(n > 0 ? n : 1, sizeof *c->ceps);
+        c->n_ceps = (int *)calloc(n > 0 ? n : 1, sizeof *c->n_ceps);
+    }
+    return c;
+}
+
+void sea_chunk_free(sea_chunk *c)
+{
+    int u;
+    if (!c) return;
+    for (u = 0; u < c->n; u++) {
+        if (c->in) free(c->in[u]);
+        if (c->out) free(c->out[u]);
+        if (c->mask) free(c->mask[u]);
+        if (c->ceps) free(c->ceps[u]);
+    }
+    free(c->in);
+    free(c->out);
+    free(c->len);
+    free(c->used);
+    free(c->mask);
+    free(c->ceps);
+    free(c->n_ceps);
+    free(c);
+}
+
+void sea_queue_init(sea_queue *q, int cap, int producers)
+{
+    memset(q, 0, sizeof *q);
+    pthread_mutex_init(&q->mu, NULL);
+    pthread_cond_init(&q->can_put, NULL);
+    pthread_cond_init(&q->can_get, NULL);
+    q->cap = cap > 0 ? cap : 1;
+    q->producers = producers;
+}
+
+void sea_queue_put(sea_queue *q, sea_chunk *c)
+{
+    pthread_mutex_lock(&q->mu);
+    while (q->count >= q->cap) pthread_cond_wait(&q->can_put, &q->mu);
+    c->next = NULL;
+    if (q->tail) q->tail->next = c; else q->head = c;
+    q->tail = c;
+    q->count++;
+    pthread_cond_signal(&q->can_get);
+    pthread_mutex_unlock(&q->mu);
+}
+
+sea_chunk *sea_queue_get(sea_queue *q)
+{
+    sea_chunk *c;
+    pthread_mutex_lock(&q->mu);
+    while (q->count == 0 && q->producers > 0) pthread_cond_wait(&q->can_get, &q->mu);
+    c = q->head;
+    if (c) {
+        q->head = c->next;
+        if (!q->head) q->tail = NULL;
+        q->count--;
+        pthread_cond_signal(&q->can_put);
+    }
+    pthread_mutex_unlock(&q->mu);
+    return c;
+}
+
+void sea_queue_producer_done(sea_queue *q)
+{
+    pthread_mutex_lock(&q->mu);
+    if (q->producers > 0) q->producers--;
+    if (q->producers == 0) pthread_cond_broadcast(&q->can_get);
+    pthread_mutex_unlock(&q->mu);
+}
+
+void sea_queue_destroy(sea_queue *q)
+{
+    pthread_mutex_destroy(&q->mu);
+    pthread_cond_destroy(&q->can_put);
+    pthread_cond_destroy(&q->can_get);
+}

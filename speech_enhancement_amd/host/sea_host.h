@@ -45,4 +45,36 @@ int sea_wav_write(const char *path, const short *data, long n, int fs);
 int sea_mask_text_write(FILE *fp, const char *id, const float *mask64, long rows);
 long sea_mask_text_read(FILE *fp, char *id_out /* SEA_FILE_LEN, may be NULL */, float *mask64, long max_rows);
 
+
+/* ---- the drivers' pipeline: reader thread(s) -> device thread(s) -> writer thread(s) ------------------------------
+ * A chunk of the utterance list travels through two bounded queues, so that chunk k+1's WAVs are read and chunk
+ * k-1's written while chunk k is on a GPU (the reference reads, processes and writes one file at a time,
+ * etsi/cpp/main.cpp:43-67; its batch tool does that from a pool of threads, aurora_speech_enhancement.cpp:311-327). */
+#include <pthread.h>
+typedef struct sea_chunk {
+    int first, n;          /* ids[first .. first + n) of the list (resynth: ids[used[u]]) */
+    int *used;             /* resynth: list index of utterance u of the chunk */
+    short **in, **out;
+    float **mask;          /* resynth: [rows][64] per utterance */
+    float **ceps;          /* etsi --ceps: [n_ceps][14] per utterance */
+    int *n_ceps;
+    long *len;
+    int rc;
+    struct sea_chunk *next;
+} sea_chunk;
+sea_chunk *sea_chunk_new(int first, int n, int with_mask, int with_ceps);
+void sea_chunk_free(sea_chunk *c);
+
+typedef struct {
+    pthread_mutex_t mu;
+    pthread_cond_t can_put, can_get;
+    sea_chunk *head, *tail;
+    int count, cap, producers; /* closed when producers reaches 0 */
+} sea_queue;
+void sea_queue_init(sea_queue *q, int cap, int producers);
+void sea_queue_put(sea_queue *q, sea_chunk *c);        /* blocks while the queue is full */
+sea_chunk *sea_queue_get(sea_queue *q);                /* blocks; NULL once every producer is done and the queue is empty */
+void sea_queue_producer_done(sea_queue *q);
+void sea_queue_destroy(sea_queue *q);
+
 #endif

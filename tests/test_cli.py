@@ -177,9 +177,37 @@ def test_cli_etsi_denoise_end_to_end(tmp_path, oracle):
         y, fs = _read_wav(out + f"resynth_e/{i}_e_resynth.wav")
         assert fs == 16000 and len(y) == len(x)
         want = oracle.etsi_denoise(x, fill=0)
-        assert np.abs(y.astype(int) - want.astype(int)).max() <= 2
+        assert np.array_equal(y, want), i
         assert not np.any(y[len(x) // 80 * 80:])
     assert all(i in open(out + "run.log").read() for i in ids)
+
+
+@pytest.mark.gpu
+def test_cli_config1_one_four_second_wav(tmp_path, oracle):
+    """SURVEY 8(d) Config 1 through the file CLI: ONE 4-s 16 kHz WAV in, the denoised WAV and (--ceps) the cepstra
+    of the explicit NoiseSup -> CompCeps chain out: 800 NoiseSup input frames, 796 output frames (4 frames of
+    latency, the first 320 samples zero), 794 cepstral frames of 14 coefficients -- and every sample and every
+    coefficient against the oracle (which tests/test_oracle.py pins to the reference itself)."""
+    import struct as st
+    from speech_enhancement_amd import corpus
+    _need_bins()
+    x = corpus.synth_utterance(1, 64000)
+    out, ids = _workspace(tmp_path, [x], with_nummix=True)
+    r = subprocess.run([os.path.join(BIN, "etsi_denoise"), out + "cfg.txt", "--ceps"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    y, fs = _read_wav(out + f"resynth_e/{ids[0]}_e_resynth.wav")
+    tr = oracle.ns_trace(x, want_state=False)
+    assert fs == 16000 and len(y) == 64000 and len(x) // 80 == 800
+    assert tr["nout"] == 796 and tr["nceps"] == 794
+    assert np.array_equal(y, oracle.etsi_denoise(x, fill=0))
+    assert not np.any(y[:320]) and np.any(y[320:400])
+    raw = open(out + f"resynth_e/{ids[0]}_e_resynth.ceps", "rb").read()
+    rows, cols = st.unpack("<ii", raw[:8])
+    assert (rows, cols) == (794, 14)
+    ceps = np.frombuffer(raw[8:], dtype="<f4").reshape(rows, cols)
+    d = float(np.abs(ceps - tr["ceps"]).max())
+    print("config 1 cepstra worst |delta| =", d)
+    assert d <= 1e-3
 
 
 @pytest.mark.gpu
@@ -199,5 +227,27 @@ def test_cli_resynth_end_to_end(tmp_path, oracle, ibm):
     for i, x, m in zip(ids, utts, masks):
         y, fs = _read_wav(out + f"resynth_e/{i}_e_resynth.wav")
         m7 = np.array([[float(f"{v:.7f}") for v in row] for row in m], dtype=np.float32)
-        want = oracle.resynth64(x if i != ids[1] else x, m7, binary=ibm)
-        assert len(y) == len(x) and np.abs(y.astype(int) - want.astype(int)).max() <= 2
+        want = oracle.resynth64(x, m7, binary=ibm)
+        assert len(y) == len(x) and np.array_equal(y, want), i
+
+
+@pytest.mark.gpu
+def test_cli_resynth_device_thread_pool(tmp_path, oracle):
+    """The resynthesis driver's reader -> device threads -> writers pipeline: 40 utterances in chunks of 16
+    (SEA_CHUNK), two device threads sharing the one card (SEA_DEVICES=2); every output WAV equals the oracle whatever
+    thread and chunk produced it, in whatever order the chunks finished."""
+    from speech_enhancement_amd import corpus
+    _need_bins()
+    utts = [corpus.synth_utterance(400 + k, 1600 + 160 * (k % 9) + (k % 5)) for k in range(40)]
+    masks = [corpus.synth_mask(400 + k, len(x)) for k, x in enumerate(utts)]
+    out, ids = _workspace(tmp_path, utts, with_nummix=False)
+    with open(out + "result.txt", "w") as f:
+        for i, m in zip(ids, masks):
+            corpus.write_mask_text(f, i, m)
+    r = subprocess.run([os.path.join(BIN, "enhance_resyth_subband"), out + "cfg.txt"], capture_output=True, text=True,
+                       env=dict(os.environ, SEA_DEVICES="2", SEA_CHUNK="16"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    for i, x, m in zip(ids, utts, masks):
+        y, fs = _read_wav(out + f"resynth_e/{i}_e_resynth.wav")
+        m7 = np.array([[float(f"{v:.7f}") for v in row] for row in m], dtype=np.float32)
+        assert fs == 16000 and np.array_equal(y, oracle.resynth64(x, m7)), i
