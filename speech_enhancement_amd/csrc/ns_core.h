@@ -695,19 +695,31 @@ __device__ __forceinline__ void ns_front(const float *buf, float *work, float *p
 }
 
 /* FFTtoPSD (NoiseSup.c:249-270) of one transformed frame of the dual transform -> psd[0..64]
- * (addresses from the tables: the work area is swizzled) */
+ * (addresses from the tables: the work area is swizzled).  All five operands are fetched unconditionally (lane 0's
+ * unused Im(0) address is element 0, the Nyquist bin is a broadcast read) and made opaque before the arithmetic:
+ * written with conditional loads the compiler builds a branch -- and an LDS latency -- per operand. */
+struct PsdOps {
+    float re0, re1, im1, im0, ny;
+};
+__device__ __forceinline__ void psd_load(const float *work, const Fft2Regs &R, PsdOps &o)
+{
+    o.re0 = fft_at(work, R.psdA[0] & 0xffffu), o.re1 = fft_at(work, R.psdA[0] >> 16);
+    o.im1 = fft_at(work, R.psdA[1] & 0xffffu), o.im0 = fft_at(work, R.psdA[1] >> 16);
+    o.ny = fft_at(work, R.nyq);
+}
+__device__ __forceinline__ void psd_store(const PsdOps &o, float *psd, int lane)
+{
+    const float p0 = (lane > 0) ? (o.re0 * o.re0 + o.im0 * o.im0) : (o.re0 * o.re0);
+    const float p1 = o.re1 * o.re1 + o.im1 * o.im1;
+    psd[lane] = (p0 + p1) * 0.5f;
+    if (lane == 0) psd[64] = o.ny * o.ny;
+}
 __device__ __forceinline__ void psd_from_fft2(const float *work, float *psd, const Fft2Regs &R, int lane)
 {
-    const float re0 = fft_at(work, R.psdA[0] & 0xffffu), re1 = fft_at(work, R.psdA[0] >> 16);
-    const float im1 = fft_at(work, R.psdA[1] & 0xffffu);
-    const float im0 = (lane > 0) ? fft_at(work, R.psdA[1] >> 16) : 0.0f;
-    const float p0 = (lane > 0) ? (re0 * re0 + im0 * im0) : (re0 * re0);
-    const float p1 = re1 * re1 + im1 * im1;
-    psd[lane] = (p0 + p1) * 0.5f;
-    if (lane == 0) {
-        const float ny = fft_at(work, R.nyq);
-        psd[64] = ny * ny;
-    }
+    PsdOps o;
+    psd_load(work, R, o);
+    asm volatile("" : "+v"(o.re0), "+v"(o.re1), "+v"(o.im1), "+v"(o.im0), "+v"(o.ny));
+    psd_store(o, psd, lane);
 }
 
 /* Two FRONT halves in one wave: frame A (stage buffer bufA) and frame B (bufB) are windowed,
@@ -715,7 +727,9 @@ __device__ __forceinline__ void psd_from_fft2(const float *work, float *psd, con
  * wave-uniform; an inactive side is fed zeros and its PSD is not written.  work: 512 floats. */
 /* the lane's eight windowed input elements for rfft256_head8: element n0 + 32 * bitrev3(j) of its transform's
  * frame (lanes 0..31: bufA, 32..63: bufB; analysis window on buf[60..259], zero beyond element 199 -- literal
- * zeros, as the reference pads, not products with a zero weight).  An inactive side is fed zeros. */
+ * zeros, as the reference pads, not products with a zero weight).  An inactive side is fed zeros.
+ * The eight samples are fetched unconditionally (60 + 255 < 320: always inside the stage buffer) and made opaque
+ * before the selects, so that they travel as ONE batch of LDS reads instead of a branch and a latency each. */
 __device__ __forceinline__ void ns_window8(const float *bufA, bool actA, const float *bufB, bool actB,
                                            const float (&win8)[8], int lane, float (&e)[8])
 {
@@ -723,12 +737,16 @@ __device__ __forceinline__ void ns_window8(const float *bufA, bool actA, const f
     const bool hiHalf = lane >= 32;
     const float *buf = hiHalf ? bufB : bufA;
     const bool act = hiHalf ? actB : actA;
+    constexpr int kRev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = buf[60 + n0 + 32 * kRev3[j]];
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        constexpr int kRev3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
         const int idx = n0 + 32 * kRev3[j];
-        const float v = buf[60 + idx]; /* 60 + 255 < 320: always inside the stage buffer */
-        e[j] = (act && idx < SEA_WIN) ? v * win8[j] : 0.0f;
+        const float p = v[j] * win8[j];
+        e[j] = (act && idx < SEA_WIN) ? p : 0.0f;
     }
 }
 
@@ -740,8 +758,14 @@ __device__ __forceinline__ void ns_front_dual(const float *bufA, bool actA, floa
     float e[8];
     ns_window8(bufA, actA, bufB, actB, win8, lane, e);
     rfft256_dual<ADDR_LDS>(e, work, fft);
-    if (actA) psd_from_fft2(work, psdA, fft, lane);
-    if (actB) psd_from_fft2(work + 256, psdB, fft, lane);
+    /* both PSDs' operands in one batch of reads */
+    PsdOps a, b;
+    psd_load(work, fft, a);
+    psd_load(work + 256, fft, b);
+    asm volatile("" : "+v"(a.re0), "+v"(a.re1), "+v"(a.im1), "+v"(a.im0), "+v"(a.ny), "+v"(b.re0), "+v"(b.re1), "+v"(b.im1),
+                 "+v"(b.im0), "+v"(b.ny));
+    if (actA) psd_store(a, psdA, lane);
+    if (actB) psd_store(b, psdB, lane);
     wave_sync();
 }
 
@@ -836,6 +860,45 @@ __device__ __forceinline__ void ns_fir_apply(const float *fir, const float *buf,
         *reinterpret_cast<float2 *>(dst + 2 * lane) = make_float2(y0, y1);
     }
     wave_sync();
+}
+
+/* ApplyWF for the helper wave: the same 17-tap sums as ns_fir_apply, left in registers (lanes 0..39: outputs 2l and
+ * 2l + 1; other lanes: unspecified), together with what the DC-offset filter needs next -- the differences
+ * d[n] = y[n] - y[n-1] (NoiseSup.c:190-194; y[-1] = lastIn, the previous frame's last filter output) taken across
+ * lanes with a one-lane DPP shift instead of a trip through LDS.  Returns y[79] (the next lastIn) in all lanes. */
+__device__ __forceinline__ float ns_fir_dif(const float *fir, const float *buf, int lane, float lastIn, float &d0, float &d1)
+{
+    float c[SEA_NTAP];
+#pragma unroll
+    for (int k4 = 0; k4 < 16; k4 += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(&fir[k4]);
+        c[k4] = v.x;
+        c[k4 + 1] = v.y;
+        c[k4 + 2] = v.z;
+        c[k4 + 3] = v.w;
+    }
+    c[16] = fir[16];
+    float x[18];
+    const int l = (lane < 40) ? lane : 39; /* every lane computes (no divergence); lanes >= 40 repeat lane 39 */
+    const float *src = buf + 72 + 2 * l;   /* x[m] = buf[72 + 2l + m] */
+#pragma unroll
+    for (int m = 0; m < 18; m += 2) {
+        const float2 v = *reinterpret_cast<const float2 *>(src + m);
+        x[m] = v.x;
+        x[m + 1] = v.y;
+    }
+    float y0 = 0.0f, y1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SEA_NTAP; ++k) {
+        y0 += c[k] * x[16 - k];
+        y1 += c[k] * x[17 - k];
+    }
+    /* y1 of the lane below; lane 0 keeps `old` = lastIn (wave_shr:1 has no source lane for it) */
+    const float below = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lastIn), __float_as_int(y1), 0x138 /* wave_shr:1 */,
+                                                                   0xf, 0xf, false));
+    d0 = y0 - below;
+    d1 = y1 - y0;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y1), 39));
 }
 
 template <bool LDSBASIS, bool RL = false>
@@ -1150,10 +1213,20 @@ __device__ __forceinline__ bool dc_filter(const float *dif, float *out, float &y
  * instruction = 14 clk per step, FMA alone 10), so the serial pass keeps only every fifth value -- lane 32 + j
  * captures y[5j - 1], the value segment j starts from, under a one-bit scalar mask -- and lanes 32..47 then
  * recompute their five outputs each, in parallel, with the same FMA on the same operands. */
+/* the exactness condition of the float-FMA form of the DC recurrence for one step (see dc_filter) */
+__device__ __forceinline__ bool dc_step_ok(float d, float yPrev)
+{
+    const float ad = fabsf(d), ay = fabsf(yPrev);
+    return (ad == 0.0f) || (ay == 0.0f) || (ay >= ad * 0x1p-16f && ay <= ad * 0x1p26f && ad < 0x1p100f && ad > 0x1p-100f);
+}
+
+/* *unsafe (optional): set when some step of the DC chain fails dc_step_ok -- checked by the sixteen recomputing lanes
+ * on the values they hold in registers (start value, five inputs, five outputs); the caller then redoes the frame on
+ * the exact path (dc_redo_exact).  nullptr: the caller verifies through LDS (dc_verify). */
 template <int CHUNKS>
 __device__ __forceinline__ void helper_chains(const float *sq, const float *den, const float *dif, float *out,
                                               const float *zero4, float &vadSum, float &denSum,
-                                              float &y, int lane)
+                                              float &y, int lane, bool *unsafe = nullptr)
 {
     const int g = lane >> 4;
     const float *src = (g == 0) ? sq : ((g == 1) ? den : dif);
@@ -1202,18 +1275,37 @@ __device__ __forceinline__ void helper_chains(const float *sq, const float *den,
         }
         if (c + 1 < CHUNKS) __builtin_amdgcn_sched_barrier(0);
     }
-    /* sixteen lanes redo their five steps from the captured start values */
+    /* sixteen lanes redo their five steps from the captured start values (the inputs are made opaque here: nothing that
+     * depends on them -- the exactness checks -- may be scheduled into the serial chain above, where every extra
+     * instruction costs its full issue time) */
+    asm volatile("" : "+v"(d5[0]), "+v"(d5[1]), "+v"(d5[2]), "+v"(d5[3]), "+v"(d5[4]), "+v"(cap));
     {
         float v = cap;
+        bool bad = false;
 #pragma unroll
         for (int k = 0; k < kSeg; ++k) {
+            if (unsafe) bad |= !dc_step_ok(d5[k], v);
             v = __fmaf_rn(0.9990234375f, v, d5[k]);
             if (lane >= 32 && lane < 48) out[kSeg * seg + k] = v;
         }
+        if (unsafe) *unsafe = __ballot(bad && lane >= 32 && lane < 48) != 0ull;
     }
     vadSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
     denSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 16));
     y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 32));
+    wave_sync();
+}
+
+/* the exact path of the DC recurrence over one frame (double multiply-add, rounded to float per sample), for the
+ * frames on which the FMA form's exactness condition failed */
+__device__ __forceinline__ void dc_redo_exact(const float *dif, float *out, float y0, float &y)
+{
+    wave_sync();
+    y = y0;
+    for (int n = 0; n < SEA_HOP; ++n) {
+        y = (float)__fma_rn(0.9990234375, (double)y, (double)dif[n]);
+        out[n] = y;
+    }
     wave_sync();
 }
 

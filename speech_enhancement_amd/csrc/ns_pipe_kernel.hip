@@ -51,6 +51,11 @@ constexpr int kPipeWaves = 4;
 #ifndef SEA_ROLE_MASK
 #define SEA_ROLE_MASK 127
 #endif
+/* timing-only ablations of the helper wave (results wrong by construction): 1 no second-stage FIR, 2 no VAD log,
+ * 4 no output store, 8 no chains */
+#ifndef SEA_ABL_S
+#define SEA_ABL_S 0
+#endif
 
 
 /* timing-only diagnostic (-DSEA_NS_TIMING): shader-clock cycles each role of workgroup 0 spends
@@ -77,9 +82,15 @@ struct RoleTimer {
 #define NS_T_MID rt_.mid()
 #define NS_T_END rt_.end()
 #define NS_T_FLUSH(slot) rt_.flush(slot)
+#ifdef SEA_NS_TIMING_NOCK /* role totals only: the checkpoints inside a role cost ~100 clk each and move the schedule */
+#define NS_T_CK(k)
+#define NS_T_CK_DECL unsigned long long ck_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define NS_T_CK_START
+#else
 #define NS_T_CK(k) do { const unsigned long long c_ = clock64(); ck_[k] += c_ - ckt_; ckt_ = c_; } while (0)
 #define NS_T_CK_DECL unsigned long long ck_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ckt_ = 0
 #define NS_T_CK_START ckt_ = clock64()
+#endif
 #define NS_T_CK_FLUSH do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int q_ = 0; q_ < 8; ++q_) g_ns_timing[8 + q_] = ck_[q_]; } while (0)
 #else
 #define NS_T_CK(k)
@@ -410,37 +421,53 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
             }
             const bool haveOut = fo >= 0 && fo < nfr;
             if (haveOut) produced = (SEA_ROLE_MASK & 64) && L.r34[fo & 1].produced != 0;
-            if (doVad) {
+            /* everything the chains need goes into LDS in one batch: the squares of the VAD frame and the DC filter's
+             * input differences, straight from the second-stage FIR's registers (stage-1 17-tap FIR, NoiseSup.c:324-340) */
+            {
                 const float *frame = L.circ[0] + (tp & (kSlots - 1)) * kSlotLen;
-                const float x = frame[lane];
-                L.ssq[lane] = x * x;
-                if (lane < 16) {
-                    const float yv = frame[64 + lane];
-                    L.ssq[64 + lane] = yv * yv;
+                float x = 0.0f, yv = 0.0f, d0 = 0.0f, d1 = 0.0f;
+                if (doVad) {
+                    x = frame[lane];
+                    if (lane < 16) yv = frame[64 + lane];
                 }
-            }
-            if (produced) { /* stage-1 17-tap FIR (NoiseSup.c:324-340), then the DC differences */
-                const Rec34 &r = L.r34[fo & 1];
-                if (SEA_FIR_IN_S) ns_fir_apply(r.fir, L.circ[1] + window_base(r.tick), L.sfir, lane);
-                const float *y2 = SEA_FIR_IN_S ? L.sfir : r.out;
-                const float xm1 = (lane == 0) ? dcX : y2[lane - 1];
-                L.sdif[lane] = y2[lane] - xm1;
-                if (lane < 16) L.sdif[64 + lane] = y2[64 + lane] - y2[63 + lane];
-                dcX = y2[79];
+                if (produced) {
+                    const Rec34 &r = L.r34[fo & 1];
+                    if (SEA_ABL_S & 1) {
+                        d0 = d1 = dcX;
+                    } else if (SEA_FIR_IN_S) {
+                        dcX = ns_fir_dif(r.fir, L.circ[1] + window_base(r.tick), lane, dcX, d0, d1);
+                    } else {
+                        const float *y2 = r.out;
+                        const float xm1 = (lane == 0) ? dcX : y2[lane - 1];
+                        L.sdif[lane] = y2[lane] - xm1;
+                        if (lane < 16) L.sdif[64 + lane] = y2[64 + lane] - y2[63 + lane];
+                        dcX = y2[79];
+                    }
+                }
+                if (doVad) {
+                    L.ssq[lane] = x * x;
+                    if (lane < 16) L.ssq[64 + lane] = yv * yv;
+                }
+                if (produced && SEA_FIR_IN_S && lane < 40) *reinterpret_cast<float2 *>(&L.sdif[2 * lane]) = make_float2(d0, d1);
             }
             NS_T_CK(0);
             if (doVad || doDen || produced) {
                 wave_sync();
                 float vadSum, denTotal, y = dcY;
-                helper_chains<ADDR_LDS ? 10 : 4>(L.ssq, denSrc, L.sdif, L.sout, L.szero, vadSum, denTotal, y, lane);
+                if (SEA_ABL_S & 8) {
+                    vadSum = L.ssq[3] + 64.0f, denTotal = denSrc[5], y = L.sdif[7];
+                } else
+                    helper_chains<ADDR_LDS ? 10 : 4>(L.ssq, denSrc, L.sdif, L.sout, L.szero, vadSum, denTotal, y, lane);
                 NS_T_CK(1);
                 if (doVad) {
-                    const float en = vad_frame_energy(vadSum);
+                    const float en = (SEA_ABL_S & 2) ? vadSum : vad_frame_energy(vadSum);
                     if (lane == 0) L.frameEn[(tp + 2) & (kSlots - 1)] = en;
                 }
                 NS_T_CK(2);
                 if (doDen && lane == 0) L.denSum[td & (kSlots - 1)] = denTotal;
                 if (produced) {
+                    /* (checking the recurrence's exactness condition on the sixteen recomputing lanes' registers instead
+                     * was measured slower: five checks in a row per lane against two per lane here) */
                     dc_verify(L.sdif, L.sout, dcY, y, lane);
                     dcY = y;
                     if (firstOut < 0) firstOut = (int)fo;
@@ -450,7 +477,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
             if (haveOut) {
                 int ln = lane; /* 80-VGPR form: recomputed, or the per-lane store address lives in scratch (see F's intake) */
                 if (ADDR_LDS) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-                if (ln < 40) {
+                if (ln < 40 && !(SEA_ABL_S & 4)) {
                     uint32_t packed = 0u;
                     if (produced) {
                         const float2 v = *reinterpret_cast<const float2 *>(&L.sout[2 * ln]);

@@ -372,23 +372,49 @@ __device__ __forceinline__ void load_fft2_regs(Fft2Regs &R, const sea_fft_tables
     for (int q = 0; q < 4; ++q) R.head8[q] = t->fft8Addr[q][lane] + both;
 }
 
-template <int S, bool ADDR_LDS>
-__device__ __forceinline__ void fft2_level(float *work, const Fft2Regs &R)
-{
-    const unsigned kind = R.kind[S];
+/* One split-radix level of the dual transform in three pieces, so that the caller can put the NEXT level's operand
+ * reads right behind this level's result stores and keep the stored registers alive across them: a wave's LDS
+ * operations execute in order, so the reads see the stores without any wait -- but when a read's destination register is
+ * also the data register of a store still in flight the compiler must wait for that store first (it did: one
+ * s_waitcnt per read, i.e. a second LDS latency per level).  fft2_keep() after the reads makes the allocator give the
+ * reads registers of their own. */
+struct Fft2Ops {
+    float x[8];
     unsigned a01, a23, b01, b23;
+};
+
+template <int S, bool ADDR_LDS>
+__device__ __forceinline__ void fft2_load(const float *work, const Fft2Regs &R, Fft2Ops &o)
+{
     if (ADDR_LDS) {
         const uint4 ad = R.addrLds[S * 64];
-        a01 = ad.x, a23 = ad.y, b01 = ad.z, b23 = ad.w;
+        o.a01 = ad.x, o.a23 = ad.y, o.b01 = ad.z, o.b23 = ad.w;
     } else {
-        a01 = R.addr[S][0], a23 = R.addr[S][1], b01 = R.addr[S][2], b23 = R.addr[S][3];
+        o.a01 = R.addr[S][0], o.a23 = R.addr[S][1], o.b01 = R.addr[S][2], o.b23 = R.addr[S][3];
     }
-    const float x1 = fft_at(work, a01 & 0xffffu), x2 = fft_at(work, a01 >> 16);
-    const float x3 = fft_at(work, a23 & 0xffffu), x4 = fft_at(work, a23 >> 16);
-    const float x5 = fft_at(work, b01 & 0xffffu), x6 = fft_at(work, b01 >> 16);
-    const float x7 = fft_at(work, b23 & 0xffffu), x8 = fft_at(work, b23 >> 16);
+    o.x[0] = fft_at(work, o.a01 & 0xffffu), o.x[1] = fft_at(work, o.a01 >> 16);
+    o.x[2] = fft_at(work, o.a23 & 0xffffu), o.x[3] = fft_at(work, o.a23 >> 16);
+    o.x[4] = fft_at(work, o.b01 & 0xffffu), o.x[5] = fft_at(work, o.b01 >> 16);
+    o.x[6] = fft_at(work, o.b23 & 0xffffu), o.x[7] = fft_at(work, o.b23 >> 16);
+}
+
+/* keeps eight values in registers up to this point and orders the LDS accesses around it (no instruction) */
+__device__ __forceinline__ void fft2_keep(const float (&v)[8])
+{
+    asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]) : "memory");
+}
+
+/* Both butterfly kinds are evaluated by every lane and the lane's own kind selects the results: a wave executes both
+ * sides of a divergent branch anyway, and without the branch the two independent dependency chains interleave and the
+ * compiler sees that the operand loads have been consumed (with the branch it had to protect the next level's loads
+ * against the -- impossible -- path on which nobody consumed them: one s_waitcnt per load). */
+template <int S>
+__device__ __forceinline__ void fft2_butterfly(const Fft2Regs &R, const Fft2Ops &in, float (&o)[8])
+{
+    const bool tw = R.kind[S] == SEA_BF_TWIDDLE;
+    const float x1 = in.x[0], x2 = in.x[1], x3 = in.x[2], x4 = in.x[3], x5 = in.x[4], x6 = in.x[5], x7 = in.x[6], x8 = in.x[7];
     float o1, o2, o3, o4, o5, o6, o7, o8;
-    if (kind == SEA_BF_TWIDDLE) { /* rfft.c:145-174 */
+    { /* SEA_BF_TWIDDLE, rfft.c:145-174 */
         const float cc1 = R.tw[S][0], ss1 = R.tw[S][1], cc3 = R.tw[S][2], ss3 = R.tw[S][3];
 #if SEA_FFT_PACKED
         /* the same 24 operations on register pairs (v_pk_mul_f32 / v_pk_add_f32: each half rounded like the
@@ -427,30 +453,49 @@ __device__ __forceinline__ void fft2_level(float *work, const Fft2Regs &R)
         o5 = x5 - t4;
         o2 = x5 + t4;
 #endif
-    } else { /* SEA_BF_PAIR: plain butterfly on the a-quadruple (rfft.c:110-113), pi/4 butterfly on
-                the b-quadruple (rfft.c:120-125; the exact multiply form proven in fft_level) */
+    }
+    float p1, p3, p4, p5, p6, p7, p8;
+    { /* SEA_BF_PAIR: plain butterfly on the a-quadruple (rfft.c:110-113), pi/4 butterfly on
+         the b-quadruple (rfft.c:120-125; the exact multiply form proven in fft_level) */
         const float t1 = x4 + x3;
-        o4 = x4 - x3;
-        o3 = x1 - t1;
-        o1 = x1 + t1;
-        o2 = x2;
+        p4 = x4 - x3;
+        p3 = x1 - t1;
+        p1 = x1 + t1;
         const float u1 = (float)((double)(x7 + x8) * 0.70710678118654752440);
         const float u2 = (float)((double)(x7 - x8) * 0.70710678118654752440);
-        o8 = x6 - u1;
-        o7 = -x6 - u1;
-        o6 = x5 - u2;
-        o5 = x5 + u2;
+        p8 = x6 - u1;
+        p7 = -x6 - u1;
+        p6 = x5 - u2;
+        p5 = x5 + u2;
     }
-    if (kind != SEA_BF_NONE) {
-        fft_at(work, a01 & 0xffffu) = o1;
-        fft_at(work, a01 >> 16) = o2;
-        fft_at(work, a23 & 0xffffu) = o3;
-        fft_at(work, a23 >> 16) = o4;
-        fft_at(work, b01 & 0xffffu) = o5;
-        fft_at(work, b01 >> 16) = o6;
-        fft_at(work, b23 & 0xffffu) = o7;
-        fft_at(work, b23 >> 16) = o8;
+    o[0] = tw ? o1 : p1, o[1] = tw ? o2 : x2, o[2] = tw ? o3 : p3, o[3] = tw ? o4 : p4;
+    o[4] = tw ? o5 : p5, o[5] = tw ? o6 : p6, o[6] = tw ? o7 : p7, o[7] = tw ? o8 : p8;
+}
+
+template <int S>
+__device__ __forceinline__ void fft2_store(float *work, const Fft2Regs &R, const Fft2Ops &in, const float (&o)[8])
+{
+    if (R.kind[S] != SEA_BF_NONE) {
+        fft_at(work, in.a01 & 0xffffu) = o[0];
+        fft_at(work, in.a01 >> 16) = o[1];
+        fft_at(work, in.a23 & 0xffffu) = o[2];
+        fft_at(work, in.a23 >> 16) = o[3];
+        fft_at(work, in.b01 & 0xffffu) = o[4];
+        fft_at(work, in.b01 >> 16) = o[5];
+        fft_at(work, in.b23 & 0xffffu) = o[6];
+        fft_at(work, in.b23 >> 16) = o[7];
     }
+}
+
+/* one complete level (load, butterfly, store) */
+template <int S, bool ADDR_LDS>
+__device__ __forceinline__ void fft2_level(float *work, const Fft2Regs &R)
+{
+    Fft2Ops in;
+    float o[8];
+    fft2_load<S, ADDR_LDS>(work, R, in);
+    fft2_butterfly<S>(R, in, o);
+    fft2_store<S>(work, R, in, o);
 }
 
 /* the register-resident start of rfft256 (bit reversal, length-2 and n2=4 butterflies) for one
@@ -536,6 +581,21 @@ __device__ __forceinline__ void rfft256_head8(float (&e)[8], float *work, const 
     }
 }
 
+/* levels S0 .. S1 chained: level k+1's operand reads go out right behind level k's stores (see Fft2Ops) */
+template <int S0, int S1, bool ADDR_LDS>
+__device__ __forceinline__ void fft2_levels(float *work, const Fft2Regs &R, float (&prev)[8])
+{
+    Fft2Ops in;
+    fft2_load<S0, ADDR_LDS>(work, R, in);
+    fft2_keep(prev);
+    float o[8];
+    fft2_butterfly<S0>(R, in, o);
+    fft2_store<S0>(work, R, in, o);
+    wave_sync();
+    if constexpr (S0 < S1) fft2_levels<S0 + 1, S1, ADDR_LDS>(work, R, o);
+    else fft2_keep(o);
+}
+
 template <bool ADDR_LDS>
 __device__ __forceinline__ void rfft256_dual_lo(float (&e)[8], float *work, const Fft2Regs &R)
 {
@@ -561,8 +621,14 @@ __device__ __forceinline__ void rfft256_dual_hi(float *work, const Fft2Regs &R)
 template <bool ADDR_LDS>
 __device__ __forceinline__ void rfft256_dual(float (&e)[8], float *work, const Fft2Regs &R)
 {
+#ifdef SEA_FFT_UNCHAINED
     rfft256_dual_lo<ADDR_LDS>(e, work, R);
     rfft256_dual_hi<ADDR_LDS>(work, R);
+#else
+    rfft256_head8(e, work, R);
+    wave_sync();
+    fft2_levels<1, 5, ADDR_LDS>(work, R, e);
+#endif
 }
 
 /* float -> int16 exactly as the reference's (short) cast behaves on x86-64: truncate toward zero
