@@ -116,7 +116,7 @@ __device__ __forceinline__ float uniform_f(float v)
  * lane-redundant critical chains:  x = m 2^e, m in [sqrt(1/2), sqrt 2), f = (m-1)/(m+1),
  * ln m = 2 f (1 + f^2/3 + f^4/5 + ... + f^22/23), ln x = e ln2_hi + (e ln2_lo + ln m).
  * Measured against 40-digit references by tests/test_gpu_parity.py::test_selftest_log. */
-__device__ __forceinline__ double ns_ln(double x)
+__device__ __forceinline__ double ns_ln_series(double x)
 {
     const long long bits = __double_as_longlong(x);
     int e = (int)((bits >> 52) & 0x7ff) - 1023;
@@ -150,6 +150,52 @@ __device__ __forceinline__ double ns_ln(double x)
     /* ln2 split so that e * ln2_hi is exact for |e| < 2^10 */
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     return __fma_rn(de, ln2_hi, __fma_rn(de, ln2_lo, lnm));
+}
+
+
+/* The same logarithm, table-driven (round 3): both call sites sit on the two longest role waves of the pipelined
+ * kernel and the series above is a chain of ~30 dependent double-precision instructions.  Here
+ *     x = m 2^e, m in [sqrt 1/2, sqrt 2);   i = interval of m (256 intervals of 2^15 float patterns, ns_logtab.inc)
+ *     r = m c_i - 1      exact: m is a float (both sites pass floats), c_i has 26 significant bits, |r| <= 2^-9
+ *     ln x = e ln2 + (th_i + tl_i) + (r - r^2/2 + r^3/3 - r^4/4 + r^5/5 - r^6/6)
+ * ~11 dependent double instructions and one 24-byte scalar table read.  th + tl = -ln c_i to 106 bits; the interval
+ * around 1 has c = 1, th = tl = 0, so ln x keeps its relative accuracy where it vanishes.  Truncation r^7/7 is below
+ * 2^-56 of r; measured against 40-digit references by test_selftest_log_accuracy, and both complete call sites are
+ * swept over every float argument against the double-double slow path by sea_selftest_log_guard.
+ * The argument must be a positive normal FLOAT (as a double). */
+static __device__ const double kNsLogTab[256][3] = {
+#include "ns_logtab.inc"
+};
+template <bool UNI = false> /* UNI: the argument is wave-uniform -> the table row comes through a scalar load */
+__device__ __forceinline__ double ns_ln(double x)
+{
+#ifdef SEA_LN_SERIES
+    return ns_ln_series(x);
+#else
+    const unsigned fb = __float_as_uint((float)x); /* exact: x is a float */
+    int e = (int)(fb >> 23) - 127;
+    unsigned mb = (fb & 0x007fffffu) | 0x3f800000u; /* m in [1, 2) */
+    const bool big = mb > 0x3FB504F2u;               /* m >= sqrt 2 (as float patterns): halve it */
+    mb = big ? mb - 0x00800000u : mb;
+    e = big ? e + 1 : e;
+    unsigned idx = (mb - 0x3F3504F3u) >> 15;         /* 0 .. 255 */
+    if (UNI) idx = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+    const double *t = kNsLogTab[idx];
+    const double c = t[0], th = t[1], tl = t[2];
+    const double m = (double)__uint_as_float(mb);
+    const double r = __fma_rn(m, c, -1.0);           /* exact */
+    const double r2 = r * r;
+    double p = -1.0 / 6.0;
+    p = __fma_rn(p, r, 1.0 / 5.0);
+    p = __fma_rn(p, r, -1.0 / 4.0);
+    p = __fma_rn(p, r, 1.0 / 3.0);
+    p = __fma_rn(p, r, -0.5);
+    const double de = (double)e;
+    /* ln2 split so that e * ln2_hi is exact for |e| < 2^10 */
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double small = __fma_rn(r2, p, r) + __fma_rn(de, ln2_lo, tl);
+    return __fma_rn(de, ln2_hi, th) + small;
+#endif
 }
 
 /* ---- the guard of the lean log --------------------------------------------------------------------------
@@ -286,9 +332,10 @@ __device__ __forceinline__ float ns_vad_energy_slow(float frameSum)
 {
     return (float)(0.5 + (ns_ln_cr((double)frameSum / 64.0) / kLn2) * 16.0);
 }
+template <bool UNI = false>
 __device__ __forceinline__ float ns_vad_energy_expr(float frameSum, bool *hit = nullptr)
 { /* NoiseSup.c:391 */
-    const double v = __fma_rn(ns_ln((double)frameSum * 0.015625), 23.083120654223414 /* 16 / ln 2 */, 0.5);
+    const double v = __fma_rn(ns_ln<UNI>((double)frameSum * 0.015625), 23.083120654223414 /* 16 / ln 2 */, 0.5);
     const bool near = ns_near_float_boundary(v, 10);
     if (hit) *hit = near;
     if (__builtin_expect(near, 0)) return ns_vad_energy_slow(frameSum);
@@ -298,9 +345,10 @@ __device__ __forceinline__ float ns_aversnr_slow(float averSNR)
 {
     return (float)((20 * ns_log10_slow((double)averSNR)) / 3.0);
 }
+template <bool UNI = false>
 __device__ __forceinline__ float ns_aversnr_expr(float averSNR, bool *hit = nullptr)
 { /* NoiseSup.c:607; the caller has established (double)averSNR > 0.00001 */
-    const double v = ns_ln((double)averSNR) * 2.8952965460216789 /* 20 log10(e) / 3 */;
+    const double v = ns_ln<UNI>((double)averSNR) * 2.8952965460216789 /* 20 log10(e) / 3 */;
     const bool near = ns_near_float_boundary(v, 20);
     if (hit) *hit = near;
     if (__builtin_expect(near, 0)) return ns_aversnr_slow(averSNR);
@@ -520,7 +568,7 @@ __device__ __forceinline__ float vad_frame_energy(float frameSum)
 #ifdef SEA_LIBM_LOG
     return uniform_f((float)(0.5 + (log((double)frameSum / 64.0) / kLn2) * 16.0));
 #else
-    return uniform_f(ns_vad_energy_expr(frameSum));
+    return uniform_f(ns_vad_energy_expr<true>(uniform_f(frameSum)));
 #endif
 }
 
@@ -579,7 +627,7 @@ __device__ __forceinline__ void gain_fact_update(NsRegs &s, float noiseEn)
 #ifdef SEA_LIBM_LOG
         averSNR = (float)((20 * log10((double)averSNR)) / 3.0);
 #else /* log10(y) = ln(y) * log10(e), guarded (ns_aversnr_expr) */
-        averSNR = ns_aversnr_expr(averSNR);
+        averSNR = ns_aversnr_expr<true>(uniform_f(averSNR));
 #endif
     else
         averSNR = (float)(-100.0 / 3.0);
@@ -790,8 +838,10 @@ __device__ __forceinline__ float ns_mel_fb(const BackLds &B, const NsConst &C, i
  * lanes 0..39 produce two outputs each into dst.  Ends with wave_sync().
  * LDSBASIS: the 9x25 basis sits in LDS ([f][16], lane = row) instead of 25 VGPRs per lane. */
 template <bool LDSBASIS, bool RL = false>
-__device__ __forceinline__ void ns_idct_taps(float melOut, BackLds &B, const NsConst &C, int lane, const float *idctLds)
+__device__ __forceinline__ void ns_idct_taps(float melOut, BackLds &B, const NsConst &C, int lane, const float *idctLds,
+                                             float *firOut = nullptr /* where the 17 taps go; default B.fir */)
 {
+    float *fir = firOut ? firOut : B.fir;
     /* RL (the latency-bound kernel forms): band f's gain sits in lane f and reaches the nine row lanes through
      * v_readlane (a scalar operand of the multiply) instead of an LDS store, a fence and seven broadcast reads.
      * The issue-bound forms keep the LDS route: 25 lane reads are 25 more vector instructions. */
@@ -820,8 +870,8 @@ __device__ __forceinline__ void ns_idct_taps(float melOut, BackLds &B, const NsC
             h += B.mel[24] * (LDSBASIS ? idctLds[24 * 16 + lane] : C.idct[24]);
         }
         const float tap = h * C.irWin;
-        B.fir[8 + lane] = tap;
-        B.fir[8 - lane] = tap;
+        fir[8 + lane] = tap;
+        fir[8 - lane] = tap;
     }
     wave_sync();
 }
@@ -924,6 +974,19 @@ __device__ __forceinline__ float ns_lane_sum65(float vLo, float vHi)
     return total + vHi;
 }
 
+/* part of the in-order sum of ns_lane_sum65: terms K0 .. K1-1 added to `total` */
+template <int K0, int K1>
+__device__ __forceinline__ float ns_lane_sum_part(float total, float vLo)
+{
+    float src = vLo;
+#pragma unroll
+    for (int k = K0; k < K1; ++k) {
+        if (k > K0 && (k & 15) == 0) asm("" : "+v"(src) : "v"(total));
+        total += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src), k));
+    }
+    return total;
+}
+
 /* timing-only diagnostic (-DSEA_NS_TIMING -DSEA_NS_BACK_CK): shader clocks between checkpoints inside ns_back(),
  * accumulated by lane 0 of workgroup 0 in g_back_ck[ST * 8 + k]; read / reset through sea_debug_ns_back_ck().
  * Each checkpoint costs ~300 clk (s_memtime round trip), so the role totals of such a build are inflated. */
@@ -989,6 +1052,40 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     s.psdOk[ST] = psdOk ? 1 : 0;
     float WLo, WHi;
     auto lane_sum = [&](float vLo, float vHi) { return ns_lane_sum65(vLo, vHi); };
+#ifndef SEA_NS_NO_OVERLAP
+    if constexpr (ST == 1 && PIPE && RL && DEFER_FIR && !FD) {
+        /* The second stage of the four-wave form, fast-division domain: two chains that do not depend on each other
+         * until the gain factor is applied --
+         *   A  gains of the 65 bins -> LDS -> mel filter bank              (FilterCalc :522-560, DoMelFB)
+         *   B  in-order sum of the 65 noise magnitudes -> DoGainFact's scalars with their log10   (:600-637)
+         * written so that each half of B sits in the same basic block as a piece of A (the wave_sync between the gain
+         * store and the mel reads is a scheduling barrier): the instruction scheduler interleaves them, and the
+         * dependent-instruction latency of one chain hides behind the other's issue slots.  Same operations, same
+         * order within each sum. */
+        if (fast) {
+            noise_track1<true>(PLo, s.noiseLo[1], nb16, C.eps);
+            noise_track1<true>(PHi, s.noiseHi[1], nb16, C.eps);
+            float total = ns_lane_sum_part<0, 32>(0.0f, s.noiseLo[1]);
+            {
+                const ns_v2f nSig = {SEA_SQRT(nSigLo), SEA_SQRT(nSigHi)};
+                const ns_v2f P = {SEA_SQRT(PLo), SEA_SQRT(PHi)};
+                ns_v2f den = {s.denLo[1], s.denHi[1]};
+                const ns_v2f W = gain_bin2(P, nSig, ns_v2f{s.noiseLo[1], s.noiseHi[1]}, den);
+                s.denLo[1] = den.x;
+                s.denHi[1] = den.y;
+                B.wbuf[lane] = W.x;
+                if (lane == 0) B.wbuf[64] = W.y;
+            }
+            wave_sync();
+            total = ns_lane_sum_part<32, 64>(total, s.noiseLo[1]) + s.noiseHi[1];
+            gain_fact_update(s, total);
+            float melOut = ns_mel_fb(B, C, lane);
+            melOut = (float)((double)(s.alfaGF * melOut) + (1.0 - (double)s.alfaGF) * 1.0);
+            ns_idct_taps<PIPE, RL>(melOut, B, C, lane, idctLds, dst); /* the 17 taps straight into the consumer's record */
+            return;
+        }
+    }
+#endif
     if (fast) {
         if (SEA_NS_PAIR_BINS && RL) { /* not in the 80-VGPR form: the pairs cost registers there (9 spills, -4 %) */
             filter_bins_fast<ST>(PLo, PHi, nSigLo, nSigHi, s.noiseLo[ST], s.noiseHi[ST], s.denLo[ST], s.denHi[ST],
