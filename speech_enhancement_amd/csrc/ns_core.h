@@ -876,6 +876,67 @@ __device__ __forceinline__ void ns_idct_taps(float melOut, BackLds &B, const NsC
     wave_sync();
 }
 
+/* DoMelIDCT split between two waves (the in-order sum h[t] = sum_f W[f] basis[f][t], MelProc.c:357-378, is one chain
+ * of 25 dependent additions): the producer adds terms 0 .. K-1 and hands over the partial sums of rows 0..8 and the
+ * remaining gains; the consumer continues with terms K .. 24 in the same order, then windows and mirrors the taps.
+ * rec layout: [0..24] mel gains (only K.. are read), [28..36] partial sums of rows 0..8. */
+template <int K>
+__device__ __forceinline__ void ns_idct_head(float melOut, float *rec, int lane, const float *idctLds)
+{
+    float h = 0.0f;
+    const int l = (lane <= 8) ? lane : 8;
+#pragma unroll
+    for (int f = 0; f < K; ++f)
+        h += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(melOut), f)) * idctLds[f * 16 + l];
+    if (lane <= 8) rec[28 + lane] = h;
+    if (lane >= K && lane < SEA_NMEL) rec[lane] = melOut;
+    wave_sync();
+}
+template <int K>
+__device__ __forceinline__ void ns_idct_tail(const float *rec, const float *idctLds, float irWin, float *fir, int lane)
+{
+    const int l = (lane <= 8) ? lane : 8; /* every lane computes (no divergence), rows 0..8 store */
+    float m[SEA_NMEL], b[SEA_NMEL];
+#pragma unroll
+    for (int f = K; f < SEA_NMEL; ++f) {
+        m[f] = rec[f];
+        b[f] = idctLds[f * 16 + l];
+    }
+    float h = rec[28 + l];
+#pragma unroll
+    for (int f = K; f < SEA_NMEL; ++f) h += m[f] * b[f];
+    const float tap = h * irWin;
+    if (lane <= 8) {
+        fir[8 + lane] = tap;
+        fir[8 - lane] = tap;
+    }
+    wave_sync();
+}
+
+/* DoMelIDCT rows 0..8 + mirror + Hanning(17) for a wave that did NOT compute the mel gains: mel[0..24] in LDS (28
+ * floats, 16-byte aligned), basis idctLds[f][16], irWin = this lane's window weight; taps to fir[0..16].  Same
+ * operations in the same order as ns_idct_taps.  Ends with wave_sync(). */
+__device__ __forceinline__ void ns_idct_taps_from(const float *mel, const float *idctLds, float irWin, float *fir, int lane)
+{
+    float m[SEA_NMEL];
+#pragma unroll
+    for (int f4 = 0; f4 < 24; f4 += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(&mel[f4]);
+        m[f4] = v.x, m[f4 + 1] = v.y, m[f4 + 2] = v.z, m[f4 + 3] = v.w;
+    }
+    m[24] = mel[24];
+    const int l = (lane <= 8) ? lane : 8; /* every lane computes (no divergence), rows 0..8 store */
+    float h = 0.0f;
+#pragma unroll
+    for (int f = 0; f < SEA_NMEL; ++f) h += m[f] * idctLds[f * 16 + l];
+    const float tap = h * irWin;
+    if (lane <= 8) {
+        fir[8 + lane] = tap;
+        fir[8 - lane] = tap;
+    }
+    wave_sync();
+}
+
 /* ApplyWF (NoiseSup.c:324-340): the 17 taps fir[0..16] (wave-uniform: broadcast LDS reads) over
  * buf[80..159] with 8 samples of context either side; lanes 0..39 produce two outputs each into dst.
  * Ends with wave_sync(). */
@@ -1010,8 +1071,10 @@ __device__ unsigned long long g_back_ck[16];
  *         (summed later by the helper), the denEn registers are not touched.
  *   ST 1: the caller has loaded s.denEn0..2.
  * DEFER_FIR: stop after the IDCT and deposit the 17 filter taps in dst[0..16]; the FIR itself is then
- *   run by the consumer wave (ns_fir_apply), which has cycles to spare. */
-template <int ST, bool PIPE, bool FD = false, bool DEFER_FIR = false, bool RL = false>
+ *   run by the consumer wave (ns_fir_apply), which has cycles to spare.
+ * IDCT_HEAD = K >= 0 (with DEFER_FIR): add only the first K terms of the IDCT's sums and deposit the partial sums and
+ *   the remaining mel gains in dst (ns_idct_head); another wave finishes them into the taps (ns_idct_tail). */
+template <int ST, bool PIPE, bool FD = false, bool DEFER_FIR = false, bool RL = false, int IDCT_HEAD = -1>
 __device__ __forceinline__ void ns_back(const float *psd, const float *buf, BackLds &B, NsRegs &s,
                                         const NsConst &C, float *dst, int lane, float frameEnExt = 0.0f,
                                         float *spectOut = nullptr, const float *idctLds = nullptr,
@@ -1081,7 +1144,10 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
             gain_fact_update(s, total);
             float melOut = ns_mel_fb(B, C, lane);
             melOut = (float)((double)(s.alfaGF * melOut) + (1.0 - (double)s.alfaGF) * 1.0);
-            ns_idct_taps<PIPE, RL>(melOut, B, C, lane, idctLds, dst); /* the 17 taps straight into the consumer's record */
+            if (IDCT_HEAD >= 0)
+                ns_idct_head<(IDCT_HEAD >= 0 ? IDCT_HEAD : 0)>(melOut, dst, lane, idctLds);
+            else
+                ns_idct_taps<PIPE, RL>(melOut, B, C, lane, idctLds, dst); /* the 17 taps straight into the consumer's record */
             return;
         }
     }
@@ -1143,7 +1209,9 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
         }
     }
     NS_BACK_CK(3); /* in-order sum, gain factor */
-    if (DEFER_FIR) { /* the consumer wave applies the filter (ns_fir_apply): hand over the 17 taps */
+    if (DEFER_FIR && IDCT_HEAD >= 0) {
+        ns_idct_head<(IDCT_HEAD >= 0 ? IDCT_HEAD : 0)>(melOut, dst, lane, idctLds);
+    } else if (DEFER_FIR) { /* the consumer wave applies the filter (ns_fir_apply): hand over the 17 taps */
         ns_idct_taps<PIPE, RL>(melOut, B, C, lane, idctLds);
         if (lane < SEA_NTAP) dst[lane] = B.fir[lane];
         wave_sync();

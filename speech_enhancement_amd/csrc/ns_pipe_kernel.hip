@@ -44,6 +44,21 @@ constexpr int kPipeWaves = 4;
 #ifndef SEA_FIR_IN_S
 #define SEA_FIR_IN_S 1
 #endif
+/* 1 (experiment, off): the second-stage mel IDCT (DoMelIDCT: nine in-order sums of 25 terms) SPLIT between B1, the
+ * longest role, and the transform wave F, which has ~1000 clk of slack per frame: B1 adds the first SEA_IDCT_SPLIT
+ * terms, F the rest one beat later, then windows and mirrors the taps (one more beat of pipeline depth).  Bit-identical
+ * and measured: the role timers of the top-priority workgroup balance (whole IDCT in B1: F 3140 / B1 4100 clk per frame;
+ * 17 terms in B1: F 3650 / B1 3825, frame period 4310 -> 4060), but the bench step gets SLOWER for every split
+ * (2.27-2.35 ms against 2.19-2.23): the extra beat and LDS traffic cost the lower launch rows more than the top row
+ * gains (profiles/r03_ns_idct_split_experiment.txt). */
+#ifndef SEA_IDCT_IN_F
+#define SEA_IDCT_IN_F 0
+#endif
+#ifndef SEA_IDCT_SPLIT
+#define SEA_IDCT_SPLIT 13
+#endif
+constexpr int kLagS = (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? 5 : 4; /* beats between a frame's intake and its output store */
+constexpr int kRec34 = 4;                                        /* B1 writes at beat i, F at i + 1, S reads at i + 2 */
 /* waves per SIMD the register allocation must leave room for (= workgroups per CU of this 4-wave kernel) */
 #ifndef SEA_NS_MIN_WAVES
 #define SEA_NS_MIN_WAVES 4
@@ -116,7 +131,9 @@ struct __attribute__((aligned(16))) Rec23 { /* F -> B1 */
     float psd[68];
     int valid, tick, pad0, pad1;
 };
-struct __attribute__((aligned(16))) Rec34 { /* B1 -> S */
+struct __attribute__((aligned(16))) Rec34 { /* B1 -> F -> S */
+    float mel[40]; /* SEA_IDCT_IN_F: [k..24] second-stage mel gains (gain factor applied) whose IDCT terms F still has to
+                    * add, [28..36] B1's partial sums of rows 0..8 (ns_idct_head / ns_idct_tail) */
     float fir[20]; /* SEA_FIR_IN_S: the 17 taps of the second-stage filter, S applies them */
     float out[80]; /* otherwise: second-stage filter output before the DC-offset filter */
     int produced, tick, pad1, pad2;
@@ -131,14 +148,14 @@ struct __attribute__((aligned(16))) PipeLds {
     float ssq[80], sdif[80], sout[80]; /* scratch of S */
     float szero[4];                 /* zeros: what the shorter chain reads past its end */
     float sfir[80];                 /* second-stage filter output before the DC-offset filter */
-    float frameEn[kSlots];          /* VAD log-energy for tick t at [t & 7] */
+    float frameEn[kSlots];          /* 64 + in-order sum of squares of the VAD's frame for tick t at [t & 7] */
     float denSum[kSlots];           /* sum of denSigSE1 of tick t at [t & 7] */
     int fdFlags[kSlots];            /* speech flags of tick t at [t & 7] (frame-dropping VAD variant) */
     float idctT[SEA_NMEL * 16];     /* mel-IDCT basis rows 0..8: [f][16], shared by B0 and B1 */
     Rec01 r01[2];
     Rec12 r12[2];
     Rec23 r23[2];
-    Rec34 r34[2];
+    Rec34 r34[kRec34];
 };
 
 /* start of the 320-sample window "buf[0..319]" of the reference at tick t: buf[240..319] is the
@@ -197,7 +214,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
     }
     const long long off = a.offsets[u];
     const long long nfr = a.lengths[u] / SEA_HOP;
-    const long long niter = nfr + 4;
+    const long long niter = nfr + kLagS;
 
     for (int i = threadIdx.x; i < 2 * (kCirc + kMirror); i += 64 * kPipeWaves) (&L.circ[0][0])[i] = 0.0f;
     for (int i = threadIdx.x; i < SEA_NMEL * 16; i += 64 * kPipeWaves) L.idctT[i] = a.tables->idct[i >> 4][i & 15];
@@ -211,8 +228,8 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
         L.r12[threadIdx.x].valid = 0;
         L.r12[threadIdx.x].den[65] = L.r12[threadIdx.x].den[66] = L.r12[threadIdx.x].den[67] = 0.0f; /* read as zeros by S */
         L.r23[threadIdx.x].valid = 0;
-        L.r34[threadIdx.x].produced = 0;
     }
+    if (threadIdx.x < kRec34) L.r34[threadIdx.x].produced = 0;
     block_sync();
 
     NS_T_DECL;
@@ -228,6 +245,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
         float win8[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) win8[k] = a.tables->win8[k][lane];
+        const float irWin = a.tables->irWin[lane];
         const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in + off);
         uint32_t nextw = (lane < 40 && nfr > 0) ? in32[lane] : 0u;
         int tick = 0; /* frames seen since (and including) the first non-zero one */
@@ -294,6 +312,13 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                               L.work, fft, win8, lane);
             }
             NS_T_CK(6);
+            if (SEA_IDCT_IN_F && SEA_FIR_IN_S) { /* the taps of the frame B1 finished one beat ago */
+                const long long fg = i - 4;
+                if (fg >= 0 && fg < nfr) {
+                    Rec34 &g = L.r34[fg & (kRec34 - 1)];
+                    if (g.produced) ns_idct_tail<SEA_IDCT_SPLIT>(g.mel, L.idctT, irWin, g.fir, lane);
+                }
+            }
             v2 = v1, t2 = t1, v1 = vCur, t1 = tCur;
             vCur = 0;
             if (i + 1 < nfr) intake(i + 1);
@@ -336,8 +361,10 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                 if ((SEA_ROLE_MASK & 2) && valid && t >= 3) {
                     float *tmp = L.back[0].sq; /* FIR output staged here, then stored with its mirror */
                     int bits = 0;
+                    /* the helper wave leaves the frame's in-order sum of squares; the log-energy (NoiseSup.c:391) is taken
+                     * here, by its consumer: this wave has ~1000 clk of slack per frame, the helper wave none */
                     ns_back<0, true, FD, false, !ADDR_LDS>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
-                                         L.frameEn[t & (kSlots - 1)], o.den, L.idctT, &fd, &bits);
+                                         vad_frame_energy(L.frameEn[t & (kSlots - 1)]), o.den, L.idctT, &fd, &bits);
                     if (FD && lane == 0) L.fdFlags[t & (kSlots - 1)] = bits;
                     if (lane < 40) {
                         const float2 v = *reinterpret_cast<const float2 *>(tmp + 2 * lane);
@@ -365,7 +392,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
             const long long f = i - 3;
             if (f >= 0 && f < nfr) {
                 const Rec23 &r = L.r23[f & 1];
-                Rec34 &o = L.r34[f & 1];
+                Rec34 &o = L.r34[f & (kRec34 - 1)];
                 const int valid = r.valid, t = r.tick;
                 int produced = 0;
                 if ((SEA_ROLE_MASK & 8) && valid && t >= 5) {
@@ -373,8 +400,9 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                     s.denEn0 = L.denSum[(t - 2) & (kSlots - 1)];
                     s.denEn1 = L.denSum[(t - 1) & (kSlots - 1)];
                     s.denEn2 = L.denSum[t & (kSlots - 1)];
-                    ns_back<1, true, false, SEA_FIR_IN_S != 0, !ADDR_LDS>(r.psd, L.circ[1] + window_base(t), L.back[1], s, C,
-                                                               SEA_FIR_IN_S ? o.fir : o.out, lane, 0.0f, nullptr, L.idctT);
+                    ns_back<1, true, false, SEA_FIR_IN_S != 0, !ADDR_LDS, (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? SEA_IDCT_SPLIT : -1>(
+                        r.psd, L.circ[1] + window_base(t), L.back[1], s, C,
+                        SEA_FIR_IN_S ? (SEA_IDCT_IN_F ? o.mel : o.fir) : o.out, lane, 0.0f, nullptr, L.idctT);
                     produced = 1;
                 }
                 if (lane == 0) {
@@ -404,7 +432,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
              *     the frame B1 finished at i-1.  etsi_denoise copies zeros until the first NoiseSup
              *     output (AdvFrontEnd.c:186-190).
              * The three serial chains are independent of each other and run interleaved. */
-            const long long fp = i - 1, fd = i - 2, fo = i - 4;
+            const long long fp = i - 1, fd = i - 2, fo = i - kLagS;
             bool doVad = false, doDen = false, produced = false;
             int tp = 0, td = 0;
             const float *denSrc = L.r12[0].den;
@@ -420,7 +448,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                 denSrc = r.den;
             }
             const bool haveOut = fo >= 0 && fo < nfr;
-            if (haveOut) produced = (SEA_ROLE_MASK & 64) && L.r34[fo & 1].produced != 0;
+            if (haveOut) produced = (SEA_ROLE_MASK & 64) && L.r34[fo & (kRec34 - 1)].produced != 0;
             /* everything the chains need goes into LDS in one batch: the squares of the VAD frame and the DC filter's
              * input differences, straight from the second-stage FIR's registers (stage-1 17-tap FIR, NoiseSup.c:324-340) */
             {
@@ -431,7 +459,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                     if (lane < 16) yv = frame[64 + lane];
                 }
                 if (produced) {
-                    const Rec34 &r = L.r34[fo & 1];
+                    const Rec34 &r = L.r34[fo & (kRec34 - 1)];
                     if (SEA_ABL_S & 1) {
                         d0 = d1 = dcX;
                     } else if (SEA_FIR_IN_S) {
@@ -459,10 +487,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                 } else
                     helper_chains<ADDR_LDS ? 10 : 4>(L.ssq, denSrc, L.sdif, L.sout, L.szero, vadSum, denTotal, y, lane);
                 NS_T_CK(1);
-                if (doVad) {
-                    const float en = (SEA_ABL_S & 2) ? vadSum : vad_frame_energy(vadSum);
-                    if (lane == 0) L.frameEn[(tp + 2) & (kSlots - 1)] = en;
-                }
+                if (doVad && lane == 0) L.frameEn[(tp + 2) & (kSlots - 1)] = vadSum; /* 64 + sum of squares; B0 takes the log */
                 NS_T_CK(2);
                 if (doDen && lane == 0) L.denSum[td & (kSlots - 1)] = denTotal;
                 if (produced) {
@@ -487,7 +512,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
                     out32[fo * 40 + ln] = packed;
                 }
                 if (FD && produced && lane == 0 && a.flags_out)
-                    a.flags_out[off / 8 + 10 * fo] = (unsigned char)L.fdFlags[L.r34[fo & 1].tick & (kSlots - 1)];
+                    a.flags_out[off / 8 + 10 * fo] = (unsigned char)L.fdFlags[L.r34[fo & (kRec34 - 1)].tick & (kSlots - 1)];
                 wave_sync();
             }
             NS_T_CK(4);
