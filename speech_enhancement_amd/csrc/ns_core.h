@@ -805,7 +805,10 @@ __device__ __forceinline__ void ns_front_dual(const float *bufA, bool actA, floa
 {
     float e[8];
     ns_window8(bufA, actA, bufB, actB, win8, lane, e);
-    rfft256_dual<ADDR_LDS>(e, work, fft);
+#ifndef SEA_BIG_LAT
+#define SEA_BIG_LAT 0 /* the table-in-LDS (large-batch, issue-bound) form keeps the throughput transform: 484 vs 468 M frames/s on the configs[4] shard */
+#endif
+    rfft256_dual<ADDR_LDS, (!ADDR_LDS || SEA_BIG_LAT)>(e, work, fft);
     /* both PSDs' operands in one batch of reads */
     PsdOps a, b;
     psd_load(work, fft, a);

@@ -472,6 +472,47 @@ __device__ __forceinline__ void fft2_butterfly(const Fft2Regs &R, const Fft2Ops 
     o[4] = tw ? o5 : p5, o[5] = tw ? o6 : p6, o[6] = tw ? o7 : p7, o[7] = tw ? o8 : p8;
 }
 
+/* The throughput-bound users of the transform (rfft256, CompCeps, IRM: many waves per SIMD) keep the butterfly kinds as
+ * a divergent branch: both sides still issue, but without the eight selects and the extra live registers of the
+ * branch-free form (CompCeps 0.87 -> 1.09 ms with the branch-free form). */
+template <int S>
+__device__ __forceinline__ void fft2_butterfly_branchy(const Fft2Regs &R, const Fft2Ops &in, float (&o)[8])
+{
+    const unsigned kind = R.kind[S];
+    const float x1 = in.x[0], x2 = in.x[1], x3 = in.x[2], x4 = in.x[3], x5 = in.x[4], x6 = in.x[5], x7 = in.x[6], x8 = in.x[7];
+    float o1, o2, o3, o4, o5, o6, o7, o8;
+    if (kind == SEA_BF_TWIDDLE) { /* rfft.c:145-174 */
+        const float cc1 = R.tw[S][0], ss1 = R.tw[S][1], cc3 = R.tw[S][2], ss3 = R.tw[S][3];
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f a37 = {x3, x7}, a48 = {x4, x8}, w1 = {cc1, ss1}, w3 = {cc3, ss3};
+        v2f p1, q1, p3, q3;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p1) : "v"(a37), "v"(w1));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(q1) : "v"(a37), "v"(w1));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p3) : "v"(a48), "v"(w3));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(q3) : "v"(a48), "v"(w3));
+        const v2f T12 = p1 + q1, T34 = p3 + q3;
+        const v2f T56 = T12 + T34, D34 = T12 - T34;
+        const v2f o16 = v2f{x1, x1} + v2f{T56.x, -T56.x};
+        const v2f o25 = v2f{x5, x5} + v2f{D34.y, -D34.y};
+        const v2f o83 = v2f{T56.y, T56.y} + v2f{x6, -x6};
+        const v2f o47 = v2f{x2, -x2} - v2f{D34.x, D34.x};
+        o1 = o16.x, o6 = o16.y, o2 = o25.x, o5 = o25.y, o8 = o83.x, o3 = o83.y, o4 = o47.x, o7 = o47.y;
+    } else { /* SEA_BF_PAIR (rfft.c:110-113, :120-125) */
+        const float t1 = x4 + x3;
+        o4 = x4 - x3;
+        o3 = x1 - t1;
+        o1 = x1 + t1;
+        o2 = x2;
+        const float u1 = (float)((double)(x7 + x8) * 0.70710678118654752440);
+        const float u2 = (float)((double)(x7 - x8) * 0.70710678118654752440);
+        o8 = x6 - u1;
+        o7 = -x6 - u1;
+        o6 = x5 - u2;
+        o5 = x5 + u2;
+    }
+    o[0] = o1, o[1] = o2, o[2] = o3, o[3] = o4, o[4] = o5, o[5] = o6, o[6] = o7, o[7] = o8;
+}
+
 template <int S>
 __device__ __forceinline__ void fft2_store(float *work, const Fft2Regs &R, const Fft2Ops &in, const float (&o)[8])
 {
@@ -487,14 +528,14 @@ __device__ __forceinline__ void fft2_store(float *work, const Fft2Regs &R, const
     }
 }
 
-/* one complete level (load, butterfly, store) */
+/* one complete level (load, butterfly, store), throughput form */
 template <int S, bool ADDR_LDS>
 __device__ __forceinline__ void fft2_level(float *work, const Fft2Regs &R)
 {
     Fft2Ops in;
     float o[8];
     fft2_load<S, ADDR_LDS>(work, R, in);
-    fft2_butterfly<S>(R, in, o);
+    fft2_butterfly_branchy<S>(R, in, o);
     fft2_store<S>(work, R, in, o);
 }
 
@@ -618,17 +659,19 @@ __device__ __forceinline__ void rfft256_dual_hi(float *work, const Fft2Regs &R)
     wave_sync();
 }
 
-template <bool ADDR_LDS>
+/* LAT = true: the latency form (levels chained, branch-free butterflies) for a wave whose run time is its own chain of
+ * dependent instructions -- the transform wave of the pipelined NoiseSup kernels; LAT = false: the throughput form */
+template <bool ADDR_LDS, bool LAT = false>
 __device__ __forceinline__ void rfft256_dual(float (&e)[8], float *work, const Fft2Regs &R)
 {
-#ifdef SEA_FFT_UNCHAINED
-    rfft256_dual_lo<ADDR_LDS>(e, work, R);
-    rfft256_dual_hi<ADDR_LDS>(work, R);
-#else
-    rfft256_head8(e, work, R);
-    wave_sync();
-    fft2_levels<1, 5, ADDR_LDS>(work, R, e);
-#endif
+    if (LAT) {
+        rfft256_head8(e, work, R);
+        wave_sync();
+        fft2_levels<1, 5, ADDR_LDS>(work, R, e);
+    } else {
+        rfft256_dual_lo<ADDR_LDS>(e, work, R);
+        rfft256_dual_hi<ADDR_LDS>(work, R);
+    }
 }
 
 /* float -> int16 exactly as the reference's (short) cast behaves on x86-64: truncate toward zero
