@@ -10,8 +10,7 @@
  *                            NoiseSup outputs exist (the commented-out driver block
  *                            etsi/cpp/ParmInterface.c:275-293)
  */
-#include "sea_device.h"
-#include "sea_kernels.h"
+#include "ns_core.h" /* the kernels' own double log and its guard (ns_ln, ns_near_float_boundary, ns_ln_cr) */
 
 namespace sea {
 
@@ -108,6 +107,35 @@ namespace {
 
 constexpr int kCcT = 16;
 
+#ifndef SEA_CC_FASTLOG
+#define SEA_CC_FASTLOG 1
+#endif
+#ifndef SEA_CC_LAT
+#define SEA_CC_LAT 0
+#endif
+#ifndef SEA_CC_MELW_LDS
+#define SEA_CC_MELW_LDS 0 /* (in LDS: 15.6 KB per wave, ten waves per CU instead of twelve: 0.83 -> 1.00 ms) */
+#endif
+#ifndef SEA_CC_WAVES
+#define SEA_CC_WAVES 3 /* waves per SIMD the register allocation leaves room for (LDS allows twelve waves per CU) */
+#endif
+
+/* (float)log((double)v) for a positive normal float v, as CompCeps.c:423 / :511 take it.  The library's double log
+ * costs ~150 instructions; the kernels' own table-driven one (ns_core.h, ns_ln: within ~1.1 ulp) gives the same float
+ * unless the double lands within a few ulps of a float ROUNDING BOUNDARY -- there (probability ~2^-27 per call) the
+ * logarithm is redone in double-double arithmetic and rounded once, exactly like the two NoiseSup sites
+ * (ns_near_float_boundary; window 4 ulps: ours 1.1 + glibc's 0.52, doubled). */
+__device__ __forceinline__ float cc_logf(float v)
+{
+#if SEA_CC_FASTLOG
+    const double l = ns_ln<false>((double)v);
+    if (__builtin_expect(ns_near_float_boundary(l, 4), 0)) return (float)ns_ln_cr((double)v);
+    return (float)l;
+#else
+    return (float)log((double)v);
+#endif
+}
+
 template <bool SHARED>
 struct CcGeom {
     /* SHARED: frames of one utterance, 80 samples apart, share their samples; word x of the span (x = 0 is
@@ -124,6 +152,7 @@ struct __attribute__((aligned(16))) CcTileLds {
     float fb[kCcT][24];
     float dctT[SEA_CC_NCHAN * 16];
     float outb[kCcT * SEA_CC_NCEP];
+    float melW[SEA_CC_MELW_LDS ? SEA_CC_TAPS * 32 : 4]; /* [tap][band]: the 22 triangle weights of a band (32 lanes read 32 banks) */
 };
 
 struct CcTileConst {
@@ -132,7 +161,7 @@ struct CcTileConst {
     int qd[8], qm[8];                 /* word offsets of Data[idx], Data[idx-1] from the frame's base; qd < 0: idx >= 200 */
     unsigned pa[4], nyq;              /* byte offsets in a work area: Re(l), Im(l), Re(l+64), Im(l+64); x[128] */
     int melStart;
-    float melW[SEA_CC_TAPS];
+    float melW[SEA_CC_MELW_LDS ? 1 : SEA_CC_TAPS];
     float floorFB, floorE;
 };
 
@@ -161,8 +190,12 @@ __device__ __forceinline__ void load_cc_tile_const(CcTileConst &C, CcTileLds<SHA
     C.nyq = fft_swz(128u);
     const int band = lane & 31;
     C.melStart = (band < SEA_CC_NCHAN) ? t->melStart[band] : 0;
+    if (SEA_CC_MELW_LDS) {
+        for (int i = lane; i < SEA_CC_TAPS * 32; i += kLanes) L.melW[i] = ((i & 31) < SEA_CC_NCHAN) ? t->melW[i >> 5][i & 31] : 0.0f;
+    } else {
 #pragma unroll
-    for (int i = 0; i < SEA_CC_TAPS; ++i) C.melW[i] = (band < SEA_CC_NCHAN) ? t->melW[i][band] : 0.0f;
+        for (int i = 0; i < (SEA_CC_MELW_LDS ? 1 : SEA_CC_TAPS); ++i) C.melW[i] = (band < SEA_CC_NCHAN) ? t->melW[i][band] : 0.0f;
+    }
     C.floorFB = t->floorFB;
     C.floorE = t->floorE;
     for (int i = lane; i < SEA_CC_NCHAN * 16; i += kLanes) L.dctT[i] = t->dctT[i >> 4][i & 15];
@@ -193,7 +226,7 @@ __device__ __forceinline__ void cc_tile(CcTileLds<SHARED> &L, const CcTileConst 
                 for (int x = 1; x < 201; ++x) { const float v = p[x]; acc += v * v; }
             }
         }
-        logE = (acc < C.floorE) ? (float)-50.0 : (float)log((double)acc);
+        logE = (acc < C.floorE) ? (float)-50.0 : cc_logf(acc);
     }
     const int npair = (nv + 1) >> 1;
     for (int pr = 0; pr < npair; ++pr) {
@@ -212,7 +245,7 @@ __device__ __forceinline__ void cc_tile(CcTileLds<SHARED> &L, const CcTileConst 
             }
             e[k] = v;
         }
-        rfft256_dual<false>(e, L.work, C.fft);
+        rfft256_dual<false, SEA_CC_LAT != 0>(e, L.work, C.fft);
         /* power spectrum, products and sum in double (:451-459), both frames */
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -234,7 +267,7 @@ __device__ __forceinline__ void cc_tile(CcTileLds<SHARED> &L, const CcTileConst 
                 const float *q = L.pw[h] + C.melStart;
                 float acc = 0.0f;
 #pragma unroll
-                for (int i = 0; i < SEA_CC_TAPS; ++i) acc = acc + q[i] * C.melW[i];
+                for (int i = 0; i < SEA_CC_TAPS; ++i) acc = acc + q[i] * (SEA_CC_MELW_LDS ? L.melW[i * 32 + band] : C.melW[SEA_CC_MELW_LDS ? 0 : i]);
                 L.fb[f][band] = acc;
             }
         }
@@ -244,7 +277,7 @@ __device__ __forceinline__ void cc_tile(CcTileLds<SHARED> &L, const CcTileConst 
     for (int idx = lane; idx < nv * SEA_CC_NCHAN; idx += kLanes) {
         const int f = idx / SEA_CC_NCHAN, b = idx - f * SEA_CC_NCHAN;
         const float v = L.fb[f][b];
-        L.fb[f][b] = (v < C.floorFB) ? (float)-10.0 : (float)log((double)v);
+        L.fb[f][b] = (v < C.floorFB) ? (float)-10.0 : cc_logf(v);
     }
     wave_sync();
     /* DCT (:203-227): lane = (frame, coefficient) flattened; c = 12 is c0, logE goes to c = 13 */
@@ -275,7 +308,20 @@ __global__ __launch_bounds__(64) void compceps_frames_kernel(const float *data20
         const long long f0 = tile * kCcT;
         const int nv = (int)((nframes - f0 < kCcT) ? nframes - f0 : kCcT);
         const float *src = data201 + f0 * 201;
-        for (int i = lane; i < nv * 201; i += kLanes) L.span[i] = src[i];
+        constexpr int kBatch = 13, kIter = (kCcT * 201 + kLanes - 1) / kLanes;
+        for (int b0 = 0; b0 < kIter; b0 += kBatch) { /* requests in batches before their stores (see compceps_kernel) */
+            float sv[kBatch];
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int i = lane + kLanes * (b0 + k);
+                sv[k] = (i < nv * 201) ? src[i] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) {
+                const int i = lane + kLanes * (b0 + k);
+                if (i < nv * 201) L.span[i] = sv[k];
+            }
+        }
         wave_sync();
         cc_tile<false>(L, C, nv, coef14 + f0 * SEA_CC_NCEP, lane);
     }
@@ -314,9 +360,19 @@ __global__ __launch_bounds__(64) void compceps_kernel(CepsArgs a)
              * Data[-1] of the utterance's very first cepstral frame is the zero before the first output */
             const float *cur0 = a.den_f32 + a.offsets[u] + (f0 + j0) * SEA_HOP;
             const int nword = SEA_HOP * (nv - 1) + SEA_WIN + 1;
-            for (int x = lane; x < nword; x += kLanes) {
-                const float v = (x == 0 && j0 == 0) ? 0.0f : cur0[x - 1];
-                L.span[x + x / SEA_HOP] = v;
+            /* all of the tile's words are requested before the first is stored: written as a load-store loop the
+             * compiler waits for each of the 22 requests in turn -- ~22 HBM latencies per tile, most of the kernel's time */
+            constexpr int kReq = (SEA_HOP * (kCcT - 1) + SEA_WIN + 1 + kLanes - 1) / kLanes;
+            float sv[kReq];
+#pragma unroll
+            for (int k = 0; k < kReq; ++k) {
+                const int x = lane + kLanes * k;
+                sv[k] = (x < nword && !(x == 0 && j0 == 0)) ? cur0[x - 1] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < kReq; ++k) {
+                const int x = lane + kLanes * k;
+                if (x < nword) L.span[x + x / SEA_HOP] = sv[k];
             }
             wave_sync();
             cc_tile<true>(L, C, nv, dst, lane);
@@ -527,7 +583,7 @@ __global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
             /* frameBuf of ParmInterface.c:281 for cepstral frame j: Data[-1..199] = the float NoiseSup stream from
              * sample 80 (f0 + j) - 1 on; Data[-1] of the utterance's first cepstral frame is 0 */
             const float *cur0 = a.den_f32 + a.offsets[u] + (f0 + j0) * SEA_HOP;
-            for (int i = lane; i < nv * 201; i += kLanes) {
+            for (int i = lane; i < nv * 201; i += kLanes) { /* (batched requests as in compceps_kernel: 256 VGPRs, one wave per SIMD, slower) */
                 const int f = i / 201, x = i - f * 201;
                 L.span[i] = (x == 0 && f == 0 && j0 == 0) ? 0.0f : cur0[SEA_HOP * f + x - 1];
             }

@@ -58,7 +58,7 @@ constexpr int kPipeWaves = 4;
 #define SEA_IDCT_SPLIT 13
 #endif
 constexpr int kLagS = (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? 5 : 4; /* beats between a frame's intake and its output store */
-constexpr int kRec34 = 4;                                        /* B1 writes at beat i, F at i + 1, S reads at i + 2 */
+constexpr int kRec34 = (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? 4 : 2;    /* with the split: B1 writes at beat i, F at i + 1, S reads at i + 2 */
 /* waves per SIMD the register allocation must leave room for (= workgroups per CU of this 4-wave kernel) */
 #ifndef SEA_NS_MIN_WAVES
 #define SEA_NS_MIN_WAVES 4
@@ -132,7 +132,7 @@ struct __attribute__((aligned(16))) Rec23 { /* F -> B1 */
     int valid, tick, pad0, pad1;
 };
 struct __attribute__((aligned(16))) Rec34 { /* B1 -> F -> S */
-    float mel[40]; /* SEA_IDCT_IN_F: [k..24] second-stage mel gains (gain factor applied) whose IDCT terms F still has to
+    float mel[SEA_IDCT_IN_F ? 40 : 4]; /* SEA_IDCT_IN_F: [k..24] second-stage mel gains (gain factor applied) whose IDCT terms F still has to
                     * add, [28..36] B1's partial sums of rows 0..8 (ns_idct_head / ns_idct_tail) */
     float fir[20]; /* SEA_FIR_IN_S: the 17 taps of the second-stage filter, S applies them */
     float out[80]; /* otherwise: second-stage filter output before the DC-offset filter */
