@@ -23,7 +23,7 @@
 
 namespace sea {
 
-namespace {
+namespace p6 { /* everything of the six-wave form */
 
 constexpr int kSlots = 8;
 constexpr int kSlotLen = SEA_HOP;
@@ -96,12 +96,9 @@ __device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables 
     C.eps = t->eps;
 }
 
-} // namespace
-
 template <bool FD>
-__device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a)
+__device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
 {
-    __shared__ Pipe6Lds L;
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
@@ -373,7 +370,19 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a)
     }
 }
 
-__global__ __launch_bounds__(384, 6) void ns_denoise_pipe6_kernel(NsBatchArgs a) { ns_pipe6_body<false>(a); }
-__global__ __launch_bounds__(384, 6) void ns_denoise_pipe6_fd_kernel(NsBatchArgs a) { ns_pipe6_body<true>(a); }
+} // namespace p6
+
+#ifndef SEA_NS_BODY_ONLY
+__global__ __launch_bounds__(384, 6) void ns_denoise_pipe6_kernel(NsBatchArgs a)
+{
+    __shared__ p6::Pipe6Lds L;
+    p6::ns_pipe6_body<false>(a, L);
+}
+__global__ __launch_bounds__(384, 6) void ns_denoise_pipe6_fd_kernel(NsBatchArgs a)
+{
+    __shared__ p6::Pipe6Lds L;
+    p6::ns_pipe6_body<true>(a, L);
+}
+#endif
 
 } // namespace sea

@@ -30,7 +30,7 @@
 
 namespace sea {
 
-namespace {
+namespace p4 { /* everything of the four-wave form */
 
 constexpr int kSlots = 8;
 constexpr int kSlotLen = SEA_HOP;
@@ -194,12 +194,9 @@ __device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables 
     C.eps = t->eps;
 }
 
-} // namespace
-
 template <bool FD, bool ADDR_LDS>
-__device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
+__device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_LDS> &L)
 {
-    __shared__ PipeLds<ADDR_LDS> L;
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
@@ -526,7 +523,14 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a)
     }
 }
 
-__global__ __launch_bounds__(256, SEA_NS_MIN_WAVES) void ns_denoise_pipe_kernel(NsBatchArgs a) { ns_pipe_body<false, false>(a); }
+} // namespace p4
+
+#ifndef SEA_NS_BODY_ONLY
+__global__ __launch_bounds__(256, SEA_NS_MIN_WAVES) void ns_denoise_pipe_kernel(NsBatchArgs a)
+{
+    __shared__ p4::PipeLds<false> L;
+    p4::ns_pipe_body<false, false>(a, L);
+}
 
 /* the same arithmetic with the transform's address tables in LDS instead of VGPRs: 80 instead of 110
  * VGPRs, six workgroups per CU instead of four -- the form to launch when the batch has more than four
@@ -534,15 +538,24 @@ __global__ __launch_bounds__(256, SEA_NS_MIN_WAVES) void ns_denoise_pipe_kernel(
 #ifndef SEA_NS_BIG_WAVES
 #define SEA_NS_BIG_WAVES 6
 #endif
-__global__ __launch_bounds__(256, SEA_NS_BIG_WAVES) void ns_denoise_pipe_big_kernel(NsBatchArgs a) { ns_pipe_body<false, true>(a); }
+__global__ __launch_bounds__(256, SEA_NS_BIG_WAVES) void ns_denoise_pipe_big_kernel(NsBatchArgs a)
+{
+    __shared__ p4::PipeLds<true> L;
+    p4::ns_pipe_body<false, true>(a, L);
+}
 
 /* the same pipeline with the first stage's speech measures (SpeechQVar/Spec/Mel, VADNS) evaluated in
  * B0 and their four bits stored per output frame: input of the frame-dropping VAD */
-__global__ __launch_bounds__(256, SEA_NS_MIN_WAVES) void ns_denoise_pipe_fd_kernel(NsBatchArgs a) { ns_pipe_body<true, false>(a); }
+__global__ __launch_bounds__(256, SEA_NS_MIN_WAVES) void ns_denoise_pipe_fd_kernel(NsBatchArgs a)
+{
+    __shared__ p4::PipeLds<false> L;
+    p4::ns_pipe_body<true, false>(a, L);
+}
+#endif
 
 } // namespace sea
 
-#ifdef SEA_NS_TIMING
+#if defined(SEA_NS_TIMING) && !defined(SEA_NS_BODY_ONLY)
 extern "C" int sea_debug_ns_back_ck(unsigned long long *out16, int reset)
 {
     if (reset) {
@@ -553,14 +566,14 @@ extern "C" int sea_debug_ns_back_ck(unsigned long long *out16, int reset)
 }
 extern "C" int sea_debug_ns_wg(unsigned *out, int n_wg)
 {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sea::g_ns_wg), (size_t)n_wg * 4 * sizeof(unsigned));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sea::p4::g_ns_wg), (size_t)n_wg * 4 * sizeof(unsigned));
 }
 extern "C" int sea_debug_ns_hw(unsigned *out, int n_wg)
 {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sea::g_ns_hw), (size_t)n_wg * 4 * sizeof(unsigned));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sea::p4::g_ns_hw), (size_t)n_wg * 4 * sizeof(unsigned));
 }
 extern "C" int sea_debug_ns_timing(unsigned long long *out8)
 {
-    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(sea::g_ns_timing), 24 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(sea::p4::g_ns_timing), 24 * sizeof(unsigned long long));
 }
 #endif
