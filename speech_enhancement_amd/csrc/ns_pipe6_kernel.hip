@@ -373,12 +373,19 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
 } // namespace p6
 
 #ifndef SEA_NS_BODY_ONLY
-__global__ __launch_bounds__(384, 6) void ns_denoise_pipe6_kernel(NsBatchArgs a)
+/* launched for at most two utterances per CU (capi.hip::ns_pick_form): twelve waves per CU, three per SIMD, so the
+ * register allocation could use up to 168 VGPRs.  The plain form stays compiled for 80 (measured: 1644 against 1679 ns
+ * per frame with the looser bound, which only changes the schedule); the _fd form takes the looser bound, which
+ * removes its 7 spilled registers (91 VGPRs). */
+#ifndef SEA_NS6_BLOCKS
+#define SEA_NS6_BLOCKS 6
+#endif
+__global__ __launch_bounds__(384, SEA_NS6_BLOCKS) void ns_denoise_pipe6_kernel(NsBatchArgs a)
 {
     __shared__ p6::Pipe6Lds L;
     p6::ns_pipe6_body<false>(a, L);
 }
-__global__ __launch_bounds__(384, 6) void ns_denoise_pipe6_fd_kernel(NsBatchArgs a)
+__global__ __launch_bounds__(384, 2) void ns_denoise_pipe6_fd_kernel(NsBatchArgs a)
 {
     __shared__ p6::Pipe6Lds L;
     p6::ns_pipe6_body<true>(a, L);
