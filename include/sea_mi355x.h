@@ -244,7 +244,7 @@ int sea_selftest_log(const float *x, double *ln_out, int n);
  *   sea_selftest_log_dd     the double-double log itself on n doubles (host pointers): hi + lo
  *   sea_selftest_log_sites  both complete sites on n floats: site1 = VAD frame log-energy of frameSum = x
  *                           (x >= 64), site2 = averSNR of x (x > 1e-5); NaN outside a site's range
- *   sea_selftest_log_guard  sweeps EVERY float argument of site 1 ([64, 2^37]) or 2 (every float > 1e-5) through
+ *   sea_selftest_log_guard  sweeps EVERY float argument of site 1 (every finite float >= 64) or 2 (every float > 1e-5) through
  *                           the fast AND the slow form: stats8 = {arguments, guard hits, hits where the slow form
  *                           changed the float, hits recorded, arguments outside the guard window on which the two
  *                           forms disagree (must be 0), 0, 0, 0}; hits3 receives up to cap triples (argument, fast

@@ -185,8 +185,9 @@ __global__ __launch_bounds__(256) void selftest_log_sites_kernel(const float *x,
     }
 }
 
-/* EVERY float argument a site can see -- site 1: frameSum in [64, 2^37] (64 + 80 * 32768^2 = 2^36.3); site 2:
- * every finite float above 1e-5 -- through the site's fast form AND its slow form (double-double log, the
+/* EVERY float argument a site can see -- site 1: every finite float frameSum >= 64 (the int16 batch path stays below
+ * 64 + 80 * 32768^2 = 2^36.3; the float streaming entry points, sea_ns_stream_push / sea_ns_streams_push, can present
+ * any float); site 2: every finite float above 1e-5 -- through the site's fast form AND its slow form (double-double log, the
  * reference's literal operation sequence).  stats[0] = arguments, [1] = guard hits, [2] = hits where the slow
  * form changed the float, [3] = hits recorded, [4] = arguments OUTSIDE the guard window on which the two forms
  * disagree (must be 0: that is the guard's claim); the first `cap` hits are recorded as (argument, float of the
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void selftest_log_sites_kernel(const float *x,
 __global__ __launch_bounds__(256) void selftest_log_guard_kernel(int site, unsigned long long *stats, float *hits, int cap)
 {
     const unsigned lo = (site == 1) ? 0x42800000u /* 64 */ : 0x3727C5ADu /* first float above 1e-5 (double compare) */;
-    const unsigned hi = (site == 1) ? 0x52000000u /* 2^37 */ : 0x7F7FFFFFu;
+    const unsigned hi = 0x7F7FFFFFu; /* the largest finite float, both sites */
     unsigned long long nhit = 0, nflip = 0, ntest = 0, nmiss = 0;
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long b = (unsigned long long)lo + blockIdx.x * blockDim.x + threadIdx.x; b <= hi; b += stride) {
