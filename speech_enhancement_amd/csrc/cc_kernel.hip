@@ -583,9 +583,26 @@ __global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
             /* frameBuf of ParmInterface.c:281 for cepstral frame j: Data[-1..199] = the float NoiseSup stream from
              * sample 80 (f0 + j) - 1 on; Data[-1] of the utterance's first cepstral frame is 0 */
             const float *cur0 = a.den_f32 + a.offsets[u] + (f0 + j0) * SEA_HOP;
-            for (int i = lane; i < nv * 201; i += kLanes) { /* (batched requests as in compceps_kernel: 256 VGPRs, one wave per SIMD, slower) */
-                const int f = i / 201, x = i - f * 201;
-                L.span[i] = (x == 0 && f == 0 && j0 == 0) ? 0.0f : cur0[SEA_HOP * f + x - 1];
+#ifndef SEA_AFE_BATCH
+#define SEA_AFE_BATCH 17 /* 1: 4.03 ms for the feature pass, 6: 3.78, 13-17: 3.66 (outer loop kept rolled) */
+#endif
+            /* requests in batches before their stores, the outer loop kept rolled (fully unrolled the allocator went to
+             * 256 VGPRs + 95 AGPRs, one wave per SIMD: 3.96 -> 5.9 ms) */
+            constexpr int kIter = (kCcT * 201 + kLanes - 1) / kLanes; /* 51 */
+#pragma unroll 1
+            for (int b0 = 0; b0 < kIter; b0 += SEA_AFE_BATCH) {
+                float sv[SEA_AFE_BATCH];
+#pragma unroll
+                for (int k = 0; k < SEA_AFE_BATCH; ++k) {
+                    const int i = lane + kLanes * (b0 + k);
+                    const int f = i / 201, x = i - f * 201;
+                    sv[k] = (i < nv * 201 && !(x == 0 && f == 0 && j0 == 0)) ? cur0[SEA_HOP * f + x - 1] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < SEA_AFE_BATCH; ++k) {
+                    const int i = lane + kLanes * (b0 + k);
+                    if (i < nv * 201) L.span[i] = sv[k];
+                }
             }
             wave_sync();
             float energy = 0.0f; /* WaveProc.c:423-427, lane = frame */
