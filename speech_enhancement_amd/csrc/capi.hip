@@ -403,7 +403,7 @@ int sea_resynth64_batch(const short *d_in, short *d_out, const long long *d_offs
     if (n_utt <= 0) return 0;
     DeviceCtx *c;
     if (ctx(&c)) return 1;
-    sea::ResynthArgs a;
+    sea::ResynthArgs a = {};
     a.in = d_in;
     a.out = d_out;
     a.offsets = d_offsets;

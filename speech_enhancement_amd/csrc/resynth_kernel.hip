@@ -672,6 +672,7 @@ __global__ __launch_bounds__(256, 4) void resynth_fused_kernel(ResynthArgs a)
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    /* (issue priority by launch row, as the NoiseSup kernel has it: measured 13.55 / 13.92 against 13.56 / 13.46 ms, no gain) */
     const long long off = a.offsets[u], L = a.lengths[u];
     if (L < ((a.binary & 2) ? 160 : 320)) return; /* no mask frame fits */
     resynth_fwd_body(a, S.f, role, lane, u, off, L);
