@@ -57,6 +57,13 @@ constexpr int kPipeWaves = 4;
 #ifndef SEA_IDCT_SPLIT
 #define SEA_IDCT_SPLIT 13
 #endif
+/* > 0: the same split with the TAIL in the helper wave S, which applies the taps anyway one beat after B1 (no extra
+ * beat, no extra record): B1 adds the first 25 - SEA_IDCT_TAIL_S terms, S the last SEA_IDCT_TAIL_S, windows and mirrors */
+#ifndef SEA_IDCT_TAIL_S
+#define SEA_IDCT_TAIL_S 4 /* measured on configs[1], alternating A/B (tools/ns_ab.sh): 0: 2.19-2.24 ms, 4: 2.14-2.19, 7: 2.16-2.19, 10: 2.17-2.18 */
+#endif
+constexpr bool kIdctSplit = (SEA_IDCT_IN_F || SEA_IDCT_TAIL_S > 0) && SEA_FIR_IN_S;
+constexpr int kIdctHead = SEA_IDCT_IN_F ? SEA_IDCT_SPLIT : 25 - SEA_IDCT_TAIL_S;
 constexpr int kLagS = (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? 5 : 4; /* beats between a frame's intake and its output store */
 constexpr int kRec34 = (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? 4 : 2;    /* with the split: B1 writes at beat i, F at i + 1, S reads at i + 2 */
 /* waves per SIMD the register allocation must leave room for (= workgroups per CU of this 4-wave kernel) */
@@ -132,7 +139,7 @@ struct __attribute__((aligned(16))) Rec23 { /* F -> B1 */
     int valid, tick, pad0, pad1;
 };
 struct __attribute__((aligned(16))) Rec34 { /* B1 -> F -> S */
-    float mel[SEA_IDCT_IN_F ? 40 : 4]; /* SEA_IDCT_IN_F: [k..24] second-stage mel gains (gain factor applied) whose IDCT terms F still has to
+    float mel[kIdctSplit ? 40 : 4]; /* split IDCT: [k..24] second-stage mel gains (gain factor applied) whose IDCT terms F still has to
                     * add, [28..36] B1's partial sums of rows 0..8 (ns_idct_head / ns_idct_tail) */
     float fir[20]; /* SEA_FIR_IN_S: the 17 taps of the second-stage filter, S applies them */
     float out[80]; /* otherwise: second-stage filter output before the DC-offset filter */
@@ -397,9 +404,9 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                     s.denEn0 = L.denSum[(t - 2) & (kSlots - 1)];
                     s.denEn1 = L.denSum[(t - 1) & (kSlots - 1)];
                     s.denEn2 = L.denSum[t & (kSlots - 1)];
-                    ns_back<1, true, false, SEA_FIR_IN_S != 0, !ADDR_LDS, (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? SEA_IDCT_SPLIT : -1>(
+                    ns_back<1, true, false, SEA_FIR_IN_S != 0, !ADDR_LDS, kIdctSplit ? kIdctHead : -1>(
                         r.psd, L.circ[1] + window_base(t), L.back[1], s, C,
-                        SEA_FIR_IN_S ? (SEA_IDCT_IN_F ? o.mel : o.fir) : o.out, lane, 0.0f, nullptr, L.idctT);
+                        SEA_FIR_IN_S ? (kIdctSplit ? o.mel : o.fir) : o.out, lane, 0.0f, nullptr, L.idctT);
                     produced = 1;
                 }
                 if (lane == 0) {
@@ -418,6 +425,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
         float *outf = a.out_f32 ? a.out_f32 + off : nullptr;
         float dcX = 0.0f, dcY = 0.0f; /* prevSamples, NoiseSup.c:908-909 */
         int firstOut = -1;
+        const float irWinS = (SEA_IDCT_TAIL_S > 0) ? a.tables->irWin[lane] : 0.0f;
         NS_T_CK_DECL;
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
@@ -456,7 +464,9 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                     if (lane < 16) yv = frame[64 + lane];
                 }
                 if (produced) {
-                    const Rec34 &r = L.r34[fo & (kRec34 - 1)];
+                    Rec34 &r = L.r34[fo & (kRec34 - 1)];
+                    if (SEA_IDCT_TAIL_S > 0 && !SEA_IDCT_IN_F && SEA_FIR_IN_S) /* finish the taps B1 started */
+                        ns_idct_tail<kIdctHead>(r.mel, L.idctT, irWinS, r.fir, lane);
                     if (SEA_ABL_S & 1) {
                         d0 = d1 = dcX;
                     } else if (SEA_FIR_IN_S) {
