@@ -362,17 +362,23 @@ __global__ __launch_bounds__(64) void compceps_kernel(CepsArgs a)
             const int nword = SEA_HOP * (nv - 1) + SEA_WIN + 1;
             /* all of the tile's words are requested before the first is stored: written as a load-store loop the
              * compiler waits for each of the 22 requests in turn -- ~22 HBM latencies per tile, most of the kernel's time */
-            constexpr int kReq = (SEA_HOP * (kCcT - 1) + SEA_WIN + 1 + kLanes - 1) / kLanes;
-            float sv[kReq];
+            constexpr int kReq = (SEA_HOP * (kCcT - 1) + SEA_WIN + 1 + kLanes - 1) / kLanes; /* 22 */
+#ifndef SEA_CC_STAGE_BATCH
+#define SEA_CC_STAGE_BATCH 8 /* 22 at once: 225 VGPRs, two waves per SIMD, 0.77 ms; 8: 167 VGPRs, three waves (what the LDS allows), 0.71 ms */
+#endif
+#pragma unroll 1
+            for (int b0 = 0; b0 < kReq; b0 += SEA_CC_STAGE_BATCH) {
+                float sv[SEA_CC_STAGE_BATCH];
 #pragma unroll
-            for (int k = 0; k < kReq; ++k) {
-                const int x = lane + kLanes * k;
-                sv[k] = (x < nword && !(x == 0 && j0 == 0)) ? cur0[x - 1] : 0.0f;
-            }
+                for (int k = 0; k < SEA_CC_STAGE_BATCH; ++k) {
+                    const int x = lane + kLanes * (b0 + k);
+                    sv[k] = (x < nword && !(x == 0 && j0 == 0)) ? cur0[x - 1] : 0.0f;
+                }
 #pragma unroll
-            for (int k = 0; k < kReq; ++k) {
-                const int x = lane + kLanes * k;
-                if (x < nword) L.span[x + x / SEA_HOP] = sv[k];
+                for (int k = 0; k < SEA_CC_STAGE_BATCH; ++k) {
+                    const int x = lane + kLanes * (b0 + k);
+                    if (x < nword) L.span[x + x / SEA_HOP] = sv[k];
+                }
             }
             wave_sync();
             cc_tile<true>(L, C, nv, dst, lane);

@@ -62,6 +62,14 @@ constexpr int kPipeWaves = 4;
 #ifndef SEA_IDCT_TAIL_S
 #define SEA_IDCT_TAIL_S 4 /* measured on configs[1], alternating A/B (tools/ns_ab.sh): 0: 2.19-2.24 ms, 4: 2.14-2.19, 7: 2.16-2.19, 10: 2.17-2.18 */
 #endif
+/* 1 (experiment, off): the int16 cast and the output store (ParmInterface.c:266) of a frame run in the transform wave F one
+ * beat after the helper wave finished it (F has ~900 clk of slack per frame, S none): double-buffered output frame in
+ * LDS.  Bit-identical; measured on configs[1], alternating A/B: 2.29-2.31 ms against 2.20-2.22 (also with 6 or 8 IDCT
+ * terms moved to S on top): the extra beat costs the lower launch rows more than the top row gains, as with the
+ * IDCT split in F. */
+#ifndef SEA_STORE_IN_F
+#define SEA_STORE_IN_F 0
+#endif
 constexpr bool kIdctSplit = (SEA_IDCT_IN_F || SEA_IDCT_TAIL_S > 0) && SEA_FIR_IN_S;
 constexpr int kIdctHead = SEA_IDCT_IN_F ? SEA_IDCT_SPLIT : 25 - SEA_IDCT_TAIL_S;
 constexpr int kLagS = (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? 5 : 4; /* beats between a frame's intake and its output store */
@@ -152,7 +160,8 @@ struct __attribute__((aligned(16))) PipeLds {
     float work[512];                /* the two FFT frames of F */
     uint4 fftAddr[ADDR_LDS ? SEA_FFT_LSTAGES * 64 : 1]; /* F's butterfly operand addresses (Fft2Regs) */
     BackLds back[2];                /* scratch of B0 and B1 */
-    float ssq[80], sdif[80], sout[80]; /* scratch of S */
+    float ssq[80], sdif[80], sout[SEA_STORE_IN_F ? 2 : 1][80]; /* scratch of S (sout: the DC-filtered output frame) */
+    int outProd[2];                 /* SEA_STORE_IN_F: frame fo & 1 holds an output (1) / is a latency frame to be zero-filled (0) */
     float szero[4];                 /* zeros: what the shorter chain reads past its end */
     float sfir[80];                 /* second-stage filter output before the DC-offset filter */
     float frameEn[kSlots];          /* 64 + in-order sum of squares of the VAD's frame for tick t at [t & 7] */
@@ -218,7 +227,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
     }
     const long long off = a.offsets[u];
     const long long nfr = a.lengths[u] / SEA_HOP;
-    const long long niter = nfr + kLagS;
+    const long long niter = nfr + kLagS + (SEA_STORE_IN_F ? 1 : 0);
 
     for (int i = threadIdx.x; i < 2 * (kCirc + kMirror); i += 64 * kPipeWaves) (&L.circ[0][0])[i] = 0.0f;
     for (int i = threadIdx.x; i < SEA_NMEL * 16; i += 64 * kPipeWaves) L.idctT[i] = a.tables->idct[i >> 4][i & 15];
@@ -283,9 +292,28 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
 #ifdef SEA_NS_TIMING
         const unsigned long long clk0_ = clock64(), wall0_ = wall_clock64();
 #endif
+        uint32_t *out32F = reinterpret_cast<uint32_t *>(a.out + off);
+        float *outfF = a.out_f32 ? a.out_f32 + off : nullptr;
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
             NS_T_CK_START;
+            if (SEA_STORE_IN_F) { /* cast + store of the frame the helper wave finished one beat ago */
+                const long long fs = i - kLagS - 1;
+                if (fs >= 0 && fs < nfr) {
+                    int ln = lane;
+                    if (ADDR_LDS) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+                    const int prod = L.outProd[fs & 1];
+                    if (ln < 40) {
+                        uint32_t packed = 0u;
+                        if (prod) {
+                            const float2 v = *reinterpret_cast<const float2 *>(&L.sout[fs & 1][2 * ln]);
+                            packed = (uint32_t)cast_i16(v.x) | ((uint32_t)cast_i16(v.y) << 16);
+                            if (outfF) *reinterpret_cast<float2 *>(outfF + fs * SEA_HOP + 2 * ln) = v;
+                        }
+                        out32F[fs * 40 + ln] = packed;
+                    }
+                }
+            }
             /* stage 0, frame i */
             bool actA = false;
             Rec01 &rA = L.r01[i & 1];
@@ -453,6 +481,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                 denSrc = r.den;
             }
             const bool haveOut = fo >= 0 && fo < nfr;
+            float *soutS = L.sout[SEA_STORE_IN_F ? (fo & 1) : 0];
             if (haveOut) produced = (SEA_ROLE_MASK & 64) && L.r34[fo & (kRec34 - 1)].produced != 0;
             /* everything the chains need goes into LDS in one batch: the squares of the VAD frame and the DC filter's
              * input differences, straight from the second-stage FIR's registers (stage-1 17-tap FIR, NoiseSup.c:324-340) */
@@ -492,7 +521,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                 if (SEA_ABL_S & 8) {
                     vadSum = L.ssq[3] + 64.0f, denTotal = denSrc[5], y = L.sdif[7];
                 } else
-                    helper_chains<ADDR_LDS ? 10 : 4>(L.ssq, denSrc, L.sdif, L.sout, L.szero, vadSum, denTotal, y, lane);
+                    helper_chains<ADDR_LDS ? 10 : 4>(L.ssq, denSrc, L.sdif, soutS, L.szero, vadSum, denTotal, y, lane);
                 NS_T_CK(1);
                 if (doVad && lane == 0) L.frameEn[(tp + 2) & (kSlots - 1)] = vadSum; /* 64 + sum of squares; B0 takes the log */
                 NS_T_CK(2);
@@ -500,19 +529,23 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                 if (produced) {
                     /* (checking the recurrence's exactness condition on the sixteen recomputing lanes' registers instead
                      * was measured slower: five checks in a row per lane against two per lane here) */
-                    dc_verify(L.sdif, L.sout, dcY, y, lane);
+                    dc_verify(L.sdif, soutS, dcY, y, lane);
                     dcY = y;
                     if (firstOut < 0) firstOut = (int)fo;
                 }
                 NS_T_CK(3);
             }
-            if (haveOut) {
+            if (haveOut && SEA_STORE_IN_F) {
+                if (lane == 0) L.outProd[fo & 1] = produced ? 1 : 0;
+                if (FD && produced && lane == 0 && a.flags_out)
+                    a.flags_out[off / 8 + 10 * fo] = (unsigned char)L.fdFlags[L.r34[fo & (kRec34 - 1)].tick & (kSlots - 1)];
+            } else if (haveOut) {
                 int ln = lane; /* 80-VGPR form: recomputed, or the per-lane store address lives in scratch (see F's intake) */
                 if (ADDR_LDS) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
                 if (ln < 40 && !(SEA_ABL_S & 4)) {
                     uint32_t packed = 0u;
                     if (produced) {
-                        const float2 v = *reinterpret_cast<const float2 *>(&L.sout[2 * ln]);
+                        const float2 v = *reinterpret_cast<const float2 *>(&soutS[2 * ln]);
                         packed = (uint32_t)cast_i16(v.x) | ((uint32_t)cast_i16(v.y) << 16);
                         if (outf) *reinterpret_cast<float2 *>(outf + fo * SEA_HOP + 2 * ln) = v;
                     }
