@@ -421,6 +421,7 @@ int sea_resynth64_batch(const short *d_in, short *d_out, const long long *d_offs
         const char *e = getenv("SEA_RESYNTH");
         return e && !strcmp(e, "split");
     }();
+
     if (split) {
         hipLaunchKernelGGL(sea::resynth_fwd_kernel, dim3(n_utt), dim3(192), 0, (hipStream_t)stream, a);
         HIP_TRY(hipGetLastError());
