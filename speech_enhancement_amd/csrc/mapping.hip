@@ -87,6 +87,22 @@ struct MapThread {
     }
 };
 
+/* the calling thread's current device is put back when an entry point returns */
+struct DeviceScope {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceScope(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == dev) || hipSetDevice(dev) == hipSuccess;
+        if (prev == dev) prev = -1; /* nothing to restore */
+    }
+    ~DeviceScope()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 /* NoiseSupExports.h:14-27 */
 struct esti_denoise_in {
     float *inData;
@@ -128,7 +144,8 @@ int etsi_denoise_mapping_thread_init(void **sm_thd_pins, void *sm_glb_ins)
     *sm_thd_pins = nullptr;
     MapGlobal *g = (MapGlobal *)sm_glb_ins;
     if (!g) return 0;
-    if (hipSetDevice(g->device) != hipSuccess) return 0;
+    DeviceScope dev(g->device);
+    if (!dev.ok) return 0;
     MapThread *t = new (std::nothrow) MapThread();
     if (!t) return 0;
     t->device = g->device;
@@ -153,7 +170,8 @@ int etsi_denoise_mapping_func_Wiener(void *sm_glb_ins, void *sm_thd_ins, void *i
     if (!t || !in || !out) return fail("etsi_denoise_mapping_func_Wiener: NULL instance");
     const long nfr = in->dataNum / 80;
     if (nfr <= 0) return 0;
-    HIP_TRY(hipSetDevice(t->device));
+    DeviceScope dev(t->device);
+    if (!dev.ok) return fail("etsi_denoise_mapping_func_Wiener: cannot select device %d", t->device);
     HIP_TRY(t->ensure((size_t)nfr));
     /* the zero-frame gate (:1160-1171): float sum of squares in sample order, truncated to int */
     std::vector<long> kept;
@@ -201,13 +219,12 @@ void etsi_denoise_mapping_thread_release(void **sm_thd_pins)
 { /* :1099-1119 */
     if (!sm_thd_pins || !*sm_thd_pins) return;
     MapThread *t = (MapThread *)*sm_thd_pins;
-    int cur = -1;
-    const bool sw = hipGetDevice(&cur) == hipSuccess && cur != t->device;
-    if (sw) (void)hipSetDevice(t->device);
-    t->release_io();
-    if (t->d_state) (void)hipFree(t->d_state);
-    if (t->stream) (void)hipStreamDestroy(t->stream);
-    if (sw) (void)hipSetDevice(cur);
+    {
+        DeviceScope dev(t->device);
+        t->release_io();
+        if (t->d_state) (void)hipFree(t->d_state);
+        if (t->stream) (void)hipStreamDestroy(t->stream);
+    }
     delete t;
     *sm_thd_pins = nullptr;
 }
