@@ -201,14 +201,34 @@ int sea_ns_state_floats(void);
 int sea_ns_streams_push_fd(const float *d_in, float *d_out, int *d_produced, unsigned char *d_flags,
                            int *d_frame_counter, float *d_state, int n_streams, int nframes, int reset, void *stream);
 
+/* The 16 k-native NoiseSup variant (function/20141106_speech_enhancement/aurora_etsi/NoiseSup.cpp:1140-1407,
+ * NoiseSup.h:36-53 -- 160-sample frames, window 480, NS_FFT_LENGTH 512 transformed with NS_FFT_ORDER 8, 25 gammatone-
+ * shaped windows) on device pointers: n_streams independent streams x nframes frames, d_in / d_out
+ * [stream][frame][160]; d_state holds sea_ns16k_state_floats() floats per stream (reset != 0: thread_init's state).
+ * The frame gate of func_Wiener (:1160-1171) is applied inside.  Per frame: d_produced = outData was written;
+ * d_flags (optional) bit 0 SpeechFoundVar, 1 Spec, 2 Mel, 3 VADNS and d_frame_counter (optional) = pFrameCounter, both 0
+ * where the first stage did not run; d_wiener (optional) [stream][frame][25] = the gains func_Wiener prints, written
+ * where produced.  Parity: see oracle/ns16k_oracle.c (transform / windows / IDCT pinned against the reference's own
+ * rfft.cpp + MelProc.cpp compiled here, the frame loop unpinned). */
+int sea_ns16k_streams_push(const float *d_in, float *d_out, int *d_produced, unsigned char *d_flags, int *d_frame_counter,
+                           float *d_wiener, float *d_state, int n_streams, int nframes, int reset, void *stream);
+int sea_ns16k_state_floats(void);
+/* its host-side tables as the reference's init code lays them out (for checks against the oracle) */
+int sea_ns16k_tables_host(float *sigWindow480, float *irWindow17, int *gammaStart25, float *gamma25x128, float *idct25x25);
+/* and its table-driven transform schedule (what the kernel walks) run on the host, in place on 512 floats: rfft (x, 512, 8) */
+void sea_ns16k_fft_host(float *x512);
+
 /* The reference's batch plug-in symbols (function/20141106_speech_enhancement/aurora_etsi/NoiseSupExports.h:35-42;
  * INSTANCE / PINSTANCE / int32s of the absent aurora/aurora_include.h = void*, void**, int), as adapters over
- * sea_init / one state blob per thread instance / sea_ns_streams_push_fd (csrc/mapping.hip).  in_ins points to
+ * sea_init / one state blob per thread instance / sea_ns16k_streams_push (csrc/mapping.hip).  in_ins points to
  * {float *inData; int dataNum}, out_ins to {float *outData; int *pSpeechFoundVar, *pSpeechFoundSpec, *pSpeechFoundMel,
- * *pSpeechFoundVADNS, *pFrameCounter} (NoiseSupExports.h:14-27).  They run the etsi/ arithmetic on 80-sample frames
- * (one call consumes dataNum / 80 frames), NOT the 16 k-native gammatone-window variant the reference builds behind
- * these names; zero frames are skipped as func_Wiener skips them (aurora_etsi/NoiseSup.cpp:1160-1171); the FILE*
- * argument is ignored.  global_init / thread_init return 1 on success, func_Wiener / func return 0. */
+ * *pSpeechFoundVADNS, *pFrameCounter} (NoiseSupExports.h:14-27).  With sm_glb_res == NULL (the reference's caller,
+ * resyth_64sub_ori/cpp/aurora_etsi_test.cpp:20) they run the 16 k-native variant the reference builds behind these
+ * names: one call consumes dataNum / 160 frames, zero frames are skipped (aurora_etsi/NoiseSup.cpp:1160-1171), and
+ * the FILE* argument of func_Wiener, when not NULL, receives the line of 25 gains per second-stage frame (:1319-1328).
+ * Extension: sm_glb_res pointing to {int SamplingFrequency = 8000} (DENOISEGlobalImpl, NoiseSupExports.h:9-12) selects
+ * the etsi/ arithmetic on 80-sample frames instead (sea_ns_streams_push_fd; nothing is printed).
+ * global_init / thread_init return 1 on success, func_Wiener / func return 0. */
 int etsi_denoise_mapping_global_init(void **sm_glb_pins, void *sm_glb_res);
 int etsi_denoise_mapping_thread_init(void **sm_thd_pins, void *sm_glb_ins);
 int etsi_denoise_mapping_func_Wiener(void *sm_glb_ins, void *sm_thd_ins, void *in_ins, void *out_ins, void *fp_Wiener);

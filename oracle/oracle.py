@@ -5,6 +5,8 @@ ctypes front-end for the two checker libraries:
   * ``libsea_oracle.so``       the CPU restatement (oracle/ns_oracle.c, oracle/resynth_oracle.c)
   * ``_ref/libetsi_ref.so``    the reference's own C (etsi/cpp/*.c) compiled where it lies under
                                /root/reference, plus oracle/ref_driver*.c (only where it was built)
+  * ``_ref/libaurora_ref.so``  the two files of the 16 k-native variant that compile on their own
+                               (aurora_etsi/rfft.cpp, MelProc.cpp) + oracle/ref_driver_aurora.cpp
 
 Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg may import this
 module.  The product package ``speech_enhancement_amd`` never does.
@@ -18,6 +20,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "libsea_oracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libetsi_ref.so")
+AURORA_SO = os.path.join(_HERE, "_ref", "libaurora_ref.so")
 NSCAL = 16
 
 _c_void = ctypes.c_void_p
@@ -186,6 +189,97 @@ class Oracle(_Lib):
         cf, bw, me = (np.zeros(64, np.float32) for _ in range(3))
         self.lib.ora_resynth_channels(_ptr(cf), _ptr(bw), _ptr(me))
         return cf, bw, me
+
+    # ---- the 16 k-native NoiseSup variant (ns16k_oracle.c) ----
+    def ns16k_new(self):
+        return Ns16k(self.lib)
+
+    def ns16k_rfft(self, x, n=512, m=8):
+        y = np.array(x, dtype=np.float32, copy=True)
+        self.lib.ora16_rfft(_ptr(y), ctypes.c_int(n), ctypes.c_int(m))
+        return y
+
+    def ns16k_tables(self):
+        sw, iw, gs = np.zeros(480, np.float32), np.zeros(17, np.float32), np.zeros(25, np.int32)
+        g, d = np.zeros((25, 128), np.float32), np.zeros((25, 25), np.float32)
+        self.lib.ora16_tables(_ptr(sw), _ptr(iw), _ptr(gs), _ptr(g), _ptr(d))
+        return dict(sigWindow=sw, irWindow=iw, gammaStart=gs, gamma=g, idct=d)
+
+    def ns16k_do_gamma(self, W):
+        y = np.array(W, dtype=np.float32, copy=True)
+        assert y.size >= 128
+        self.lib.ora16_do_gamma(_ptr(y))
+        return y[:25]
+
+    def ns16k_idct(self, W):
+        y = np.array(W, dtype=np.float32, copy=True)
+        assert y.size >= 25
+        self.lib.ora16_idct(_ptr(y))
+        return y[:25]
+
+
+class Ns16k:
+    """One thread instance of the 16 k-native variant (etsi_denoise_mapping_thread_init .. thread_release)."""
+
+    UNTOUCHED = -7
+
+    def __init__(self, lib):
+        self.lib = lib
+        lib.ora16_new.restype = ctypes.c_void_p
+        lib.ora16_push.restype = ctypes.c_long
+        self.h = ctypes.c_void_p(lib.ora16_new())
+
+    def push(self, x):
+        """func_Wiener on float samples x: dict(out[n*160] float32, var, spec, mel, vadns, counter [n] int32 -- entries
+        the reference leaves untouched hold UNTOUCHED --, wiener [rows, 25])."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.size // 160
+        out = np.full(max(n, 1) * 160, float(self.UNTOUCHED), np.float32)
+        arrs = [np.full(max(n, 1), self.UNTOUCHED, np.int32) for _ in range(5)]
+        w = np.zeros((max(n, 1), 25), np.float32)
+        rows = ctypes.c_long(0)
+        self.lib.ora16_push(self.h, _ptr(x), ctypes.c_long(x.size), _ptr(out), *[_ptr(a) for a in arrs], _ptr(w), ctypes.byref(rows))
+        return dict(out=out[: n * 160], var=arrs[0][:n], spec=arrs[1][:n], mel=arrs[2][:n], vadns=arrs[3][:n], counter=arrs[4][:n],
+                    wiener=w[: rows.value])
+
+    def __del__(self):
+        if self.h:
+            self.lib.ora16_free(self.h)
+            self.h = None
+
+
+class AuroraReference:
+    """rfft.cpp + MelProc.cpp of the 16 k-native variant, compiled where they lie (present only where it was built)."""
+
+    def __init__(self):
+        if not os.path.exists(AURORA_SO):
+            raise FileNotFoundError(AURORA_SO)
+        self.lib = ctypes.CDLL(AURORA_SO)
+
+    def rfft(self, x, n=512, m=8):
+        y = np.array(x, dtype=np.float32, copy=True)
+        self.lib.ref16_rfft(_ptr(y), ctypes.c_int(n), ctypes.c_int(m))
+        return y
+
+    def tables(self):
+        gs, gl = np.zeros(25, np.int32), np.zeros(25, np.int32)
+        g, d = np.zeros((25, 128), np.float32), np.zeros((25, 25), np.float32)
+        self.lib.ref16_tables(_ptr(gs), _ptr(gl), _ptr(g), _ptr(d))
+        return dict(gammaStart=gs, gammaLen=gl, gamma=g, idct=d)
+
+    def do_gamma(self, W):
+        y = np.array(W, dtype=np.float32, copy=True)
+        self.lib.ref16_do_gamma(_ptr(y))
+        return y[:25]
+
+    def idct(self, W):
+        y = np.array(W, dtype=np.float32, copy=True)
+        self.lib.ref16_idct(_ptr(y))
+        return y[:25]
+
+
+def have_aurora_reference():
+    return os.path.exists(AURORA_SO)
 
 
 class Reference(_Lib):

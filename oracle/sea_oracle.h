@@ -58,6 +58,18 @@ int ora_subband64(const short *in, long L, short *out);
  * F = (L-320)/160+1; window 0 rectangular / 1 Hamming / 2 Hanning (asdk::SpecInfo is absent: parity unpinned). */
 int ora_irm_target(const short *pure, const short *noise, long L, long pitch, int window, float *irm);
 
+/* SURVEY 8(f) rank 4 -- the 16 k-native NoiseSup variant behind etsi_denoise_mapping_* (ns16k_oracle.c; its frame
+ * loop is parity unpinned, its transform / windows / IDCT are pinned against oracle/_ref/libaurora_ref.so) */
+typedef struct ora16_state ora16_state;
+ora16_state *ora16_new(void);
+void ora16_free(ora16_state *s);
+long ora16_push(ora16_state *s, const float *in, long dataNum, float *out, int *var, int *spec, int *mel, int *vadns,
+                int *counter, float *wiener /* [rows][25], may be NULL */, long *wiener_rows);
+void ora16_rfft(float *x, int n, int m); /* aurora_etsi/rfft.cpp as C++: the variant calls it with (512, 8) */
+void ora16_tables(float *sigWindow480, float *irWindow17, int *gammaStart25, float *gamma25x128, float *idct25x25);
+void ora16_do_gamma(float *W /* >= 128 gains in, 25 out */);
+void ora16_idct(float *W /* 25 */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,7 @@ std::mutex g_mu;
 sea_ns_tables g_ns_host;
 sea_cc_tables g_cc_host;
 sea_gt_tables g_gt_host;
+sea_ns16k_tables g_ns16_host;
 bool g_host_ready = false;
 
 void host_tables()
@@ -47,6 +48,7 @@ void host_tables()
     sea_build_ns_tables(&g_ns_host);
     sea_build_cc_tables(&g_cc_host);
     sea_build_gt_tables(&g_gt_host);
+    sea_build_ns16k_tables(&g_ns16_host);
     g_host_ready = true;
 }
 } // namespace
@@ -68,9 +70,11 @@ int ctx(DeviceCtx **out)
         HIP_TRY(hipMalloc(&c.ns, sizeof(sea_ns_tables)));
         HIP_TRY(hipMalloc(&c.cc, sizeof(sea_cc_tables)));
         HIP_TRY(hipMalloc(&c.gt, sizeof(sea_gt_tables)));
+        HIP_TRY(hipMalloc(&c.ns16, sizeof(sea_ns16k_tables)));
         HIP_TRY(hipMemcpy(c.ns, &g_ns_host, sizeof g_ns_host, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c.cc, &g_cc_host, sizeof g_cc_host, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c.gt, &g_gt_host, sizeof g_gt_host, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c.ns16, &g_ns16_host, sizeof g_ns16_host, hipMemcpyHostToDevice));
         c.ready = true;
     }
     *out = &c;
@@ -669,6 +673,38 @@ int sea_ns_streams_push_fd(const float *d_in, float *d_out, int *d_produced, uns
 }
 
 int sea_ns_state_floats(void) { return sea::kNsStateFloats; }
+
+/* ---- the 16 k-native variant (ns16k_kernel.hip) ---- */
+int sea_ns16k_streams_push(const float *d_in, float *d_out, int *d_produced, unsigned char *d_flags, int *d_frame_counter,
+                           float *d_wiener, float *d_state, int n_streams, int nframes, int reset, void *stream)
+{
+    if (n_streams <= 0 || nframes <= 0) return 0;
+    if (!d_in || !d_out || !d_produced || !d_state) return fail("sea_ns16k_streams_push: NULL buffer");
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    sea::Ns16StreamArgs a = {};
+    a.in = d_in;
+    a.out = d_out;
+    a.produced = d_produced;
+    a.flags = d_flags;
+    a.frame_counter = d_frame_counter;
+    a.wiener = d_wiener;
+    a.state = d_state;
+    a.tables = c->ns16;
+    a.nframes = nframes;
+    a.reset = reset;
+    hipLaunchKernelGGL(sea::ns16k_stream_kernel, dim3(n_streams), dim3(64), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sea_ns16k_state_floats(void) { return sea::kNs16StateFloats; }
+
+int sea_ns16k_tables_host(float *sigWindow480, float *irWindow17, int *gammaStart25, float *gamma25x128, float *idct25x25)
+{
+    sea_ns16k_plain_tables(sigWindow480, irWindow17, gammaStart25, gamma25x128, idct25x25);
+    return 0;
+}
 
 /* ------------------------------------------------------------------------------------------- */
 int sea_selftest_pi4(unsigned long long *n_mismatch)

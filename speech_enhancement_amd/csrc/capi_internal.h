@@ -24,6 +24,7 @@ struct DeviceCtx {
     sea_ns_tables *ns = nullptr;
     sea_cc_tables *cc = nullptr;
     sea_gt_tables *gt = nullptr;
+    sea_ns16k_tables *ns16 = nullptr;
     int n_cu = 256;
 };
 

@@ -663,12 +663,13 @@ struct NsFd {
 };
 __device__ __forceinline__ void fd_init(NsFd &d) { d.melMean = d.varMean = d.accTest = d.specMean = d.mel0 = d.specValues = d.speechInVADQ = 0.0f; }
 
-/* SpeechQVar: variance of the first 64 Wiener gains W (in LDS), two in-order float sums */
+/* SpeechQVar: variance of the first N = NS_FFT_LENGTH / 4 Wiener gains W (in LDS), two in-order float sums */
+template <int N = 64>
 __device__ __forceinline__ int fd_var(NsFd &d, const float *W, int fc)
 {
     float mean = 0.0f, var = 0.0f;
 #pragma unroll 4
-    for (int i = 0; i < 64; i += 4) {
+    for (int i = 0; i < N; i += 4) {
         const float4 w = *reinterpret_cast<const float4 *>(&W[i]);
         mean += w.x; var += w.x * w.x;
         mean += w.y; var += w.y * w.y;
@@ -677,7 +678,7 @@ __device__ __forceinline__ int fd_var(NsFd &d, const float *W, int fc)
     }
     mean = uniform_f(mean);
     var = uniform_f(var);
-    const float specVar = (var / 64.0f) - mean * mean / 4096.0f;
+    const float specVar = (var / (float)N) - mean * mean / (float)(N * N);
     if (fc < 15) d.varMean = (d.varMean > specVar) ? d.varMean : specVar;
     if ((double)specVar < (double)d.varMean * 1.5 && (double)specVar > (double)d.varMean * 0.85)
         d.varMean = (float)((double)d.varMean * 0.8 + (double)specVar * 0.2);

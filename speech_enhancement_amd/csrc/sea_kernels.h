@@ -43,6 +43,21 @@ struct NsStreamArgs {
     int *frame_counter;        /* optional [B][nframes]: FEParamsX::FrameCounter after the tick */
 };
 
+/* the 16 k-native variant (ns16k_kernel.hip): B independent streams, nframes frames of 160 floats each */
+constexpr int kNs16StateFloats = 2 * SEA16_BUF + 6 * 132 + 32;
+struct Ns16StreamArgs {
+    const float *in;           /* [B][nframes][160] */
+    float *out;                /* [B][nframes][160], written where produced */
+    int *produced;             /* [B][nframes]: the second stage ran (outData was written) */
+    unsigned char *flags;      /* optional [B][nframes]: bit 0 SpeechFoundVar, 1 Spec, 2 Mel, 3 VADNS; 0 where the first stage did not run */
+    int *frame_counter;        /* optional [B][nframes]: pFrameCounter, 0 where the first stage did not run */
+    float *wiener;             /* optional [B][nframes][25]: the gains func_Wiener prints, written where produced */
+    float *state;              /* [B][kNs16StateFloats] */
+    const sea_ns16k_tables *tables;
+    int nframes;
+    int reset;
+};
+
 struct CepsArgs {
     const float *den_f32;      /* float NoiseSup stream written by ns_denoise_kernel */
     const long long *offsets;  /* as above */
@@ -121,6 +136,7 @@ __global__ void ns_denoise_pipe_fd_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe6_kernel(NsBatchArgs a);    /* six waves per utterance (ns_pipe6_kernel.hip) */
 __global__ void ns_denoise_pipe6_fd_kernel(NsBatchArgs a); /* + speech flags for the frame-dropping VAD */
 __global__ void ns_stream_kernel(NsStreamArgs a);
+__global__ void ns16k_stream_kernel(Ns16StreamArgs a);
 __global__ void ns_stream_fd_kernel(NsStreamArgs a);
 __global__ void selftest_pi4_kernel(unsigned long long *mismatches);
 __global__ void selftest_dc_kernel(const float *dif, const float *y0, float *out, int *fellback, int ncases);

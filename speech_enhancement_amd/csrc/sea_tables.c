@@ -441,3 +441,224 @@ void sea_build_gt_tables(sea_gt_tables *t)
         t->olaDown[n] = 0.5 * (1.0 + cos(n * kPiHW / (160)));
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * The 16 k-native NoiseSup variant: function/20141106_speech_enhancement/aurora_etsi/
+ * NoiseSup.cpp:1034-1079 (windows), MelProc.cpp:269-341 (InitGammawindows), :464-503 (InitGammaIDCTbasis),
+ * :505-513 (ERB scale), rfft.cpp:46-181 called with (512, 8).  These files are C++: cos / sin of a float there are
+ * the float overloads (cosf / sinf below); everything else promotes as in C.
+ * ---------------------------------------------------------------------------------------- */
+static float hz_to_erb(float hz) { return (float)(21.4 * log10(hz * 0.00437 + 1.0)); }
+static float erb_to_hz(float r) { return (float)((pow(10, r / 21.4) - 1) / 0.00437); }
+
+static void gamma_windows(int start[SEA16_NGAM], float w[SEA16_NGAM][SEA16_GLEN])
+{ /* InitGammawindows (First, 80.0, 16000.0f, 2 * (129 - 1), 25, 1) */
+    const float st = 80.0f, smpl = 16000.0f;
+    const int nfft = 2 * (SEA16_NSPEC - 1);
+    float cf[SEA16_NGAM], erb[SEA16_NGAM];
+    const float lo = hz_to_erb(st), hi = hz_to_erb(smpl / 2);
+    const float step = (hi - lo) / (SEA16_NGAM - 1);
+    int i, j;
+    for (i = 0; i < SEA16_NGAM; i++) {
+        cf[i] = erb_to_hz(lo + step * i);
+        erb[i] = (float)(1.019 * 24.7 * (4.37 * cf[i] / 1000 + 1));
+    }
+    for (i = 0; i < SEA16_NGAM; i++) {
+        float norm = 0.0f;
+        start[i] = (int)((int)cf[i] * nfft / smpl);
+        for (j = 0; j < SEA16_GLEN; j++) {
+            w[i][j] = (float)(1.0 / pow((1.0 + (j * 1.0 / nfft * smpl - cf[i]) / erb[i] * (j * 1.0 / nfft * smpl - cf[i]) / erb[i]), 2));
+            norm += w[i][j];
+        }
+        for (j = 0; j < SEA16_GLEN; j++) w[i][j] /= norm;
+    }
+}
+
+static void gamma_idct(const int start[SEA16_NGAM], float basis[SEA16_NGAM][SEA16_NGAM])
+{ /* InitGammaIDCTbasis (basis, First, 25, 16000, 256) */
+    const int fs = 16000;
+    const float lin = fs / (float)(2 * (SEA16_NSPEC - 1));
+    float cf[SEA16_NGAM], df[SEA16_NGAM];
+    int i, j;
+    for (j = 0; j < SEA16_NGAM; j++) cf[j] = start[j] * lin;
+    for (j = 0; j < SEA16_NGAM; j++) {
+        if (j == 0)
+            df[j] = (cf[1] - cf[0]) / fs;
+        else if (j == SEA16_NGAM - 1)
+            df[j] = (cf[j] - cf[j - 1]) / fs;
+        else
+            df[j] = (cf[j + 1] - cf[j - 1]) / fs;
+    }
+    for (i = 0; i < SEA16_NGAM; i++)
+        for (j = 0; j < SEA16_NGAM; j++) basis[i][j] = (float)(df[j] * cos(kTwoPi * i * cf[j] / fs));
+}
+
+typedef struct {
+    sea_ns16k_tables *t;
+    int pass, n8, kind;
+} item_ctx;
+static void item_visit(int i, void *ctx)
+{
+    item_ctx *c = (item_ctx *)ctx;
+    unsigned *cnt = &c->t->fftCount[c->pass];
+    int j;
+    if (c->kind == SEA16_BF_LEN2) {
+        if (*cnt < SEA16_FFT_ITEMS) c->t->fftItem[c->pass][*cnt] = ((unsigned)SEA16_BF_LEN2 << 24) | (unsigned)i;
+        ++*cnt;
+        return;
+    }
+    if (*cnt < SEA16_FFT_ITEMS) c->t->fftItem[c->pass][*cnt] = ((unsigned)SEA16_BF_PLAIN << 24) | (unsigned)i;
+    ++*cnt;
+    if (c->n8 >= 1) { /* n4 != 1 */
+        if (*cnt < SEA16_FFT_ITEMS) c->t->fftItem[c->pass][*cnt] = ((unsigned)SEA16_BF_PI4 << 24) | (unsigned)i;
+        ++*cnt;
+    }
+    for (j = 1; j < c->n8; j++) {
+        if (*cnt < SEA16_FFT_ITEMS) c->t->fftItem[c->pass][*cnt] = ((unsigned)SEA16_BF_TWIDDLE << 24) | ((unsigned)j << 16) | (unsigned)i;
+        ++*cnt;
+    }
+}
+
+void sea_build_ns16k_tables(sea_ns16k_tables *t)
+{
+    int start[SEA16_NGAM], i, j, k, n2;
+    static float w[SEA16_NGAM][SEA16_GLEN], basis[SEA16_NGAM][SEA16_NGAM];
+    item_ctx ctx;
+    memset(t, 0, sizeof *t);
+    for (i = 0; i < SEA16_WIN; i++) /* NoiseSup.cpp:1034-1037 */
+        t->sigWindow[i] = (float)(0.5 - 0.5 * cos((kTwoPi * ((float)i + 0.5)) / (float)(short)SEA16_WIN));
+    for (j = 0; j <= 8; j++) /* :1040-1043, the half DoFilterWindowing reads (:716-725) */
+        t->irWin[j] = (float)(0.5 - 0.5 * cos((kTwoPi * ((float)(8 + j) + 0.5)) / (float)(short)SEA_NTAP));
+    gamma_windows(start, w);
+    gamma_idct(start, basis);
+    for (i = 0; i < SEA16_GLEN; i++)
+        for (j = 0; j < SEA16_NGAM; j++) t->gammaT[i][j] = w[j][i];
+    for (j = 0; j < SEA16_NGAM; j++)
+        for (i = 0; i <= 8; i++) t->idctT[j][i] = basis[i][j];
+    t->eps = (float)exp(-10.0);
+    /* the digit-reverse counter of rfft.cpp:57-79, run on the indices */
+    {
+        unsigned short pos[SEA16_NFFT];
+        int jj = 0, kk;
+        for (i = 0; i < SEA16_NFFT; i++) pos[i] = (unsigned short)i; /* pos[p] = input element now at place p */
+        for (i = 0; i < SEA16_NFFT - 1; i++) {
+            if (i < jj) {
+                unsigned short x = pos[jj];
+                pos[jj] = pos[i];
+                pos[i] = x;
+            }
+            kk = SEA16_NFFT >> 1;
+            while (kk <= jj) {
+                jj -= kk;
+                kk >>= 1;
+            }
+            jj += kk;
+        }
+        for (i = 0; i < SEA16_NFFT; i++) t->rev[pos[i]] = (unsigned short)i;
+    }
+    /* pass 0: length-2 butterflies (:82-96); passes 1..7: levels n2 = 4..256 (:99-179 with m = 8) */
+    ctx.t = t;
+    ctx.pass = 0;
+    ctx.kind = SEA16_BF_LEN2;
+    ctx.n8 = 0;
+    {
+        int is = 0, id = 4;
+        while (is < SEA16_NFFT - 1) {
+            for (i = is; i < SEA16_NFFT; i += id) item_visit(i, &ctx);
+            is = (id << 1) - 2;
+            id <<= 2;
+        }
+    }
+    for (k = 1, n2 = 2; k < 8; k++) {
+        float e;
+        n2 <<= 1;
+        ctx.pass = k;
+        ctx.kind = SEA16_BF_PLAIN;
+        ctx.n8 = n2 >> 3;
+        for_each_block(SEA16_NFFT, n2, 0, item_visit, &ctx);
+        e = (float)((kPi * 2) / n2);
+        for (j = 1; j < (n2 >> 3); j++) {
+            const float a = j * e, a3 = 3 * a;
+            t->fftTw[k][j][0] = cosf(a);
+            t->fftTw[k][j][1] = sinf(a);
+            t->fftTw[k][j][2] = cosf(a3);
+            t->fftTw[k][j][3] = sinf(a3);
+        }
+    }
+    for (k = 0; k < SEA16_FFT_PASSES; k++)
+        if (t->fftCount[k] > SEA16_FFT_ITEMS) abort(); /* the schedule no longer fits its table */
+}
+
+void sea_ns16k_plain_tables(float *sigWindow480, float *irWindow17, int *gammaStart25, float *gamma25x128, float *idct25x25)
+{
+    static float w[SEA16_NGAM][SEA16_GLEN], basis[SEA16_NGAM][SEA16_NGAM];
+    int i;
+    for (i = 0; i < SEA16_WIN; i++) sigWindow480[i] = (float)(0.5 - 0.5 * cos((kTwoPi * ((float)i + 0.5)) / (float)(short)SEA16_WIN));
+    for (i = 0; i < SEA_NTAP; i++) irWindow17[i] = (float)(0.5 - 0.5 * cos((kTwoPi * ((float)i + 0.5)) / (float)(short)SEA_NTAP));
+    gamma_windows(gammaStart25, w);
+    gamma_idct(gammaStart25, basis);
+    memcpy(gamma25x128, w, sizeof w);
+    memcpy(idct25x25, basis, sizeof basis);
+}
+
+/* The table-driven schedule run on the host, item by item as ns16k_kernel.hip's ns16_fft runs it (items of one pass
+ * in any order, passes in order): lets a CPU test check rev / fftItem / fftTw against the reference's loop nest. */
+void sea_ns16k_fft_host(float *x512)
+{
+    static sea_ns16k_tables t;
+    static int ready = 0;
+    float x[SEA16_NFFT];
+    int pass, i;
+    unsigned r;
+    if (!ready) {
+        sea_build_ns16k_tables(&t);
+        ready = 1;
+    }
+    for (i = 0; i < SEA16_NFFT; i++) x[t.rev[i]] = x512[i];
+    for (pass = 0; pass < SEA16_FFT_PASSES; pass++) {
+        const int n4 = (pass == 0) ? 0 : (1 << (pass - 1)), n8 = n4 >> 1;
+        for (r = t.fftCount[pass]; r-- > 0;) { /* backwards: the order within a pass must not matter */
+            const unsigned it = t.fftItem[pass][r];
+            const int kind = (int)(it >> 24), j = (int)((it >> 16) & 0xffu);
+            i = (int)(it & 0xffffu);
+            if (kind == SEA16_BF_LEN2) {
+                const float a0 = x[i], a1 = x[i + 1];
+                x[i] = a0 + a1;
+                x[i + 1] = a0 - a1;
+            } else if (kind == SEA16_BF_PLAIN) {
+                const int i3 = i + 2 * n4, i4 = i + 3 * n4;
+                const float x1 = x[i], x3 = x[i3], x4 = x[i4], t1 = x4 + x3;
+                x[i4] = x4 - x3;
+                x[i3] = x1 - t1;
+                x[i] = x1 + t1;
+            } else if (kind == SEA16_BF_PI4) {
+                const int i1 = i + n8, i2 = i1 + n4, i3 = i2 + n4, i4 = i3 + n4;
+                const float x1 = x[i1], x2 = x[i2], x3 = x[i3], x4 = x[i4];
+                const float t1 = (float)((double)(x3 + x4) / 1.41421356237309504880);
+                const float t2 = (float)((double)(x3 - x4) / 1.41421356237309504880);
+                x[i4] = x2 - t1;
+                x[i3] = -x2 - t1;
+                x[i2] = x1 - t2;
+                x[i1] = x1 + t2;
+            } else {
+                const float cc1 = t.fftTw[pass][j][0], ss1 = t.fftTw[pass][j][1], cc3 = t.fftTw[pass][j][2], ss3 = t.fftTw[pass][j][3];
+                const int i1 = i + j, i2 = i1 + n4, i3 = i2 + n4, i4 = i3 + n4;
+                const int i5 = i + n4 - j, i6 = i5 + n4, i7 = i6 + n4, i8 = i7 + n4;
+                const float x1 = x[i1], x2 = x[i2], x3 = x[i3], x4 = x[i4], x5 = x[i5], x6 = x[i6], x7 = x[i7], x8 = x[i8];
+                float t1 = x3 * cc1 + x7 * ss1, t2 = x7 * cc1 - x3 * ss1, t3 = x4 * cc3 + x8 * ss3, t4 = x8 * cc3 - x4 * ss3;
+                const float t5 = t1 + t3, t6 = t2 + t4;
+                t3 = t1 - t3;
+                t4 = t2 - t4;
+                x[i3] = t6 - x6;
+                x[i8] = x6 + t6;
+                x[i7] = -x2 - t3;
+                x[i4] = x2 - t3;
+                x[i6] = x1 - t5;
+                x[i1] = x1 + t5;
+                x[i5] = x5 - t4;
+                x[i2] = x5 + t4;
+            }
+        }
+    }
+    memcpy(x512, x, sizeof x);
+}

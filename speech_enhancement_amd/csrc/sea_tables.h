@@ -114,6 +114,38 @@ typedef struct {
     double olaUp[160], olaDown[160];              /* 0.5(1+cos(n pi/160 + pi)), 0.5(1+cos(n pi/160)) */
 } sea_gt_tables;
 
+/* ---- the 16 k-native NoiseSup variant behind the reference's batch plug-in symbols (SURVEY 8(f) #4;
+ * function/20141106_speech_enhancement/aurora_etsi/NoiseSup.h:36-53, NoiseSup.cpp:912-1407) ------------------------- */
+enum {
+    SEA16_HOP = 160,       /* NS_FRAME_SHIFT / NS_CUR_FRAME */
+    SEA16_WIN = 480,       /* NS_FRAME_LENGTH */
+    SEA16_AWIN = 80,       /* NS_ANALYSIS_WINDOW_8K: the window starts there in the 640-sample stage buffer */
+    SEA16_BUF = 640,       /* NS_BUFFER_SIZE */
+    SEA16_NFFT = 512,      /* NS_FFT_LENGTH, transformed with NS_FFT_ORDER 8: levels n2 = 4 .. 256 only */
+    SEA16_NSPEC = 129,     /* NS_SPEC_ORDER */
+    SEA16_NGAM = 25,       /* WF_MEL_ORDER: gammatone-shaped windows */
+    SEA16_GLEN = 128,      /* every window covers gains 0..127 (MelProc.cpp:298) */
+    SEA16_FFT_PASSES = 8,  /* pass 0: the length-2 butterflies; pass k: the L-shaped level n2 = 2^(k+1) */
+    SEA16_FFT_ITEMS = 192  /* most butterflies of one pass (asserted at build) */
+};
+enum { SEA16_BF_LEN2 = 0, SEA16_BF_PLAIN = 1, SEA16_BF_PI4 = 2, SEA16_BF_TWIDDLE = 3 };
+
+typedef struct {
+    float sigWindow[SEA16_NFFT];                          /* Hanning(480), 0 beyond */
+    unsigned short rev[SEA16_NFFT];                       /* where rfft.cpp's digit-reverse counter puts input element i */
+    unsigned fftCount[SEA16_FFT_PASSES];
+    unsigned fftItem[SEA16_FFT_PASSES][SEA16_FFT_ITEMS];  /* kind << 24 | j << 16 | block start i */
+    float fftTw[SEA16_FFT_PASSES][32][4];                 /* cc1, ss1, cc3, ss3 of twiddle index j at that pass */
+    float gammaT[SEA16_GLEN][SEA16_NGAM];                 /* [i][c]: window c's weight of gain i */
+    float idctT[SEA16_NGAM][16];                          /* [f][t], t = 0..8: the nine taps DoFilterWindowing reads */
+    float irWin[16];                                      /* [j] = Hanning(17)[8 + j], j = 0..8 */
+    float eps;
+    float pad[15];
+} sea_ns16k_tables;
+void sea_build_ns16k_tables(sea_ns16k_tables *t);
+void sea_ns16k_fft_host(float *x512); /* the table-driven transform on the host (tests) */
+void sea_ns16k_plain_tables(float *sigWindow480, float *irWindow17, int *gammaStart25, float *gamma25x128, float *idct25x25);
+
 void sea_build_ns_tables(sea_ns_tables *t);
 void sea_build_cc_tables(sea_cc_tables *t);
 void sea_build_gt_tables(sea_gt_tables *t);

@@ -418,6 +418,40 @@ def irm_target_batch(batch, pure_sub, noise_sub, window=1):
     return MaskBatch(irm, d_offs, offs, rows)
 
 
+def ns16k_streams_push(frames, state=None, reset=None):
+    """The 16 k-native NoiseSup variant behind the reference's batch plug-in symbols (aurora_etsi/NoiseSup.cpp:1140-1407;
+    SURVEY 8(f) #4): frames float32 [B, nframes, 160] on the GPU, func_Wiener's frame gate applied inside.  Returns
+    dict(out [B, nframes, 160], produced int32 [B, nframes], flags uint8 [B, nframes] (bit 0 SpeechFoundVar, 1 Spec, 2 Mel,
+    3 VADNS), counter int32 [B, nframes] (0: the first stage did not run), wiener float32 [B, nframes, 25] (rows where
+    produced), state); pass ``state`` back in to continue the same streams."""
+    torch = _torch()
+    lib = _lib.load()
+    frames = frames.contiguous()
+    B, nfr, hop = frames.shape
+    assert hop == 160 and frames.dtype == torch.float32
+    if state is None:
+        state = torch.zeros((B, lib.sea_ns16k_state_floats()), dtype=torch.float32, device=frames.device)
+        reset = True if reset is None else reset
+    out = torch.zeros_like(frames)
+    produced = torch.zeros((B, nfr), dtype=torch.int32, device=frames.device)
+    flags = torch.zeros((B, nfr), dtype=torch.uint8, device=frames.device)
+    counter = torch.zeros((B, nfr), dtype=torch.int32, device=frames.device)
+    wiener = torch.zeros((B, nfr, 25), dtype=torch.float32, device=frames.device)
+    rc = lib.sea_ns16k_streams_push(_dptr(frames), _dptr(out), _dptr(produced), _dptr(flags), _dptr(counter), _dptr(wiener),
+                                    _dptr(state), B, nfr, int(bool(reset)), _stream_ptr())
+    _lib.check(rc, "sea_ns16k_streams_push")
+    return dict(out=out, produced=produced, flags=flags, counter=counter, wiener=wiener, state=state)
+
+
+def ns16k_tables():
+    """Host-side tables of the 16 k-native variant (no GPU needed), laid out as the reference's init code builds them."""
+    lib = _lib.load()
+    sw, iw, gs = np.zeros(480, np.float32), np.zeros(17, np.float32), np.zeros(25, np.int32)
+    g, d = np.zeros((25, 128), np.float32), np.zeros((25, 25), np.float32)
+    _lib.check(lib.sea_ns16k_tables_host(*[a.ctypes.data for a in (sw, iw, gs, g, d)]), "sea_ns16k_tables_host")
+    return dict(sigWindow=sw, irWindow=iw, gammaStart=gs, gamma=g, idct=d)
+
+
 def ns_streams_push(frames, state=None, reset=None, want_flags=False):
     """Batched DoNoiseSup: frames float32 [B, nframes, 80] on the GPU.  Returns (out, produced, state);
     pass ``state`` back in to continue the same streams.  want_flags: also return (flags uint8

@@ -780,8 +780,9 @@ def test_ns_stream_plugin_flags_vs_oracle(oracle):
 
 
 def test_etsi_denoise_mapping_symbols(oracle):
-    """The reference's batch plug-in symbols (function/20141106_speech_enhancement/aurora_etsi/NoiseSupExports.h:35-42),
-    exported as adapters with 8 kHz-mode (etsi/) semantics, through the C ABI: global / thread instances, two
+    """The reference's batch plug-in symbols (function/20141106_speech_enhancement/aurora_etsi/NoiseSupExports.h:35-42)
+    in their 8 kHz-mode (etsi/ arithmetic) extension -- sm_glb_res -> {SamplingFrequency 8000}; the default, the 16 k-native
+    variant, is tests/test_gpu_ns16k.py -- through the C ABI: global / thread instances, two
     func_Wiener calls on one thread instance (the state crosses the calls), zero frames skipped without touching
     their output entries (aurora_etsi/NoiseSup.cpp:1160-1171), a second thread instance starting afresh."""
     import ctypes
@@ -805,7 +806,8 @@ def test_etsi_denoise_mapping_symbols(oracle):
     keep = np.array([n for n in range(nfr) if np.any(x[80 * n:80 * n + 80])])
     assert len(keep) == nfr - 5 - 3
     glb, thd = ctypes.c_void_p(), ctypes.c_void_p()
-    assert lib.etsi_denoise_mapping_global_init(ctypes.byref(glb), None) == 1
+    res = ctypes.c_int(8000)                          # DENOISEGlobalImpl {int SamplingFrequency}, NoiseSupExports.h:9-12
+    assert lib.etsi_denoise_mapping_global_init(ctypes.byref(glb), ctypes.byref(res)) == 1
     for attempt in range(2):                          # the second pass: a fresh thread instance gives the same again
         assert lib.etsi_denoise_mapping_thread_init(ctypes.byref(thd), glb) == 1
         xf = x.astype(np.float32)

@@ -68,6 +68,24 @@ def test_host_tables_match_oracle(oracle):
     assert np.array_equal(t["cf"], cf) and np.array_equal(t["bw"], bw) and np.array_equal(t["midEar"], me)
 
 
+def test_ns16k_host_tables_and_schedule_match_oracle(oracle):
+    """SURVEY 8(f) #4, no GPU needed: the product's tables of the 16 k-native variant (csrc/sea_tables.c) against the
+    oracle's, bit for bit, and its table-driven transform schedule (digit-reversal places, butterflies per pass,
+    twiddles: what ns16k_kernel.hip walks) run on the host against the oracle's rfft (x, 512, 8)."""
+    import ctypes
+    import speech_enhancement_amd as sea
+    t, a = sea.ns16k_tables(), oracle.ns16k_tables()
+    for k in a:
+        assert np.array_equal(t[k].view(np.uint32), a[k].view(np.uint32)), k
+    lib = sea.load()
+    rng = np.random.default_rng(5)
+    for _ in range(12):
+        x = (rng.standard_normal(512) * 10 ** rng.uniform(-3, 4)).astype(np.float32)
+        y = x.copy()
+        lib.sea_ns16k_fft_host(y.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(y.view(np.uint32), oracle.ns16k_rfft(x).view(np.uint32))
+
+
 def test_no_cpu_fallback_without_gpu():
     """On a box without a GPU the product must fail loudly, never compute on the CPU."""
     if _have_gpu():
