@@ -479,6 +479,30 @@ def also_lines(batch, ids, device, steps):
          "sea::ns_denoise_pipe_fd_kernel + sea::afe_ceps_kernel + sea::afe_vad_kernel", "afe_bytes_per_launch")
     del outb, f32, flags, fcc, f15
 
+    # the 16 k-native NoiseSup variant behind etsi_denoise_mapping_* (a side path: one wave per stream,
+    # exact divisions throughout), one stream per utterance of the shard, 400 frames of 160 int16-valued samples each
+    B, nf = batch.n_utt, 400
+    gen = torch.Generator(device=device)
+    gen.manual_seed(16)
+    fr = torch.randint(-6000, 6000, (B, nf, 160), device=device, generator=gen).float()
+    o16 = torch.zeros_like(fr)
+    pr16 = torch.zeros((B, nf), dtype=torch.int32, device=device)
+    fl16 = torch.zeros((B, nf), dtype=torch.uint8, device=device)
+    ct16 = torch.zeros((B, nf), dtype=torch.int32, device=device)
+    w16 = torch.zeros((B, nf, 25), dtype=torch.float32, device=device)
+    st16 = torch.zeros((B, lib.sea_ns16k_state_floats()), dtype=torch.float32, device=device)
+
+    def run16():
+        assert lib.sea_ns16k_streams_push(fr.data_ptr(), o16.data_ptr(), pr16.data_ptr(), fl16.data_ptr(), ct16.data_ptr(),
+                                          w16.data_ptr(), st16.data_ptr(), B, nf, 1, st) == 0
+    ker, wall = timed_steps(run16, max(2, steps // 2), 1)
+    assert int(pr16.sum().item()) == B * (nf - 4)
+    line("NoiseSup, 16 k-native variant", f"SURVEY 8(f) #4: {B} streams x {nf} frames of 160 samples through the variant behind "
+         "etsi_denoise_mapping_* (window 480, rfft (x, 512, 8), 25 gammatone-shaped windows), one wavefront per stream",
+         B * nf, "frames/s", B * nf * (2 * 640 + 100 + 9), ker, wall, "sea::ns16k_stream_kernel", "ns16k_bytes_per_launch",
+         {"rtf": wall / (B * nf * 160 / 16000.0)})
+    del fr, o16, w16
+
     # rfft256 on a streaming batch: 2^21 frames = 2 GiB in + 2 GiB out, 16 x the 256 MiB Infinity Cache (the HBM
     # figure), and 2^18 frames = 256 MiB + 256 MiB, which partly lives in that cache (kept for comparison with round 2)
     lib = sea.load()

@@ -24,6 +24,23 @@ namespace {
 constexpr int kHop = SEA16_HOP, kBuf = SEA16_BUF, kIn = SEA16_BUF - SEA16_HOP /* NS_DATA_IN_BUFFER */, kSpec = SEA16_NSPEC;
 constexpr int kSpecPad = 132;
 
+#ifndef SEA16_PIPE_SUMS
+#define SEA16_PIPE_SUMS 0 /* software-pipelined LDS requests in the frame-sum chain: 256 VGPRs + 150 AGPRs, slower */
+#endif
+#ifndef SEA16_PIPE_DC
+#define SEA16_PIPE_DC 1 /* and in the DC-offset chain */
+#endif
+
+/* timing-only diagnostic (-DSEA16_TIMING, tools/ns16k_phases.sh): shader clocks workgroup 0 spends per phase */
+#ifdef SEA16_TIMING
+__device__ unsigned long long g_ns16_ck[24];
+#define CK16_START unsigned long long ck_ = clock64()
+#define CK16(k) do { const unsigned long long c_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_ns16_ck[k] += c_ - ck_; ck_ = c_; } while (0)
+#else
+#define CK16_START
+#define CK16(k)
+#endif
+
 struct __attribute__((aligned(16))) Ns16Lds {
     float buf[2][kBuf];       /* First / SecondStageInFloatBuffer */
     float bins[6][kSpecPad];  /* noiseSE1/2, denSigSE1/2, the other slot of PSDMeanBuffer1/2 */
@@ -33,65 +50,132 @@ struct __attribute__((aligned(16))) Ns16Lds {
     float outb[kHop];         /* second-stage output frame */
     float gam[32];            /* the 25 window outputs */
     float fir[20];            /* 17 taps */
-    float gammaT[SEA16_GLEN][SEA16_NGAM];
+    float sq2[kHop];          /* VAD: squares of the first stage's current frame */
+    float ones[kSpecPad];     /* 1.0f: the "window" of the plain in-order sums that ride along with DoGamma */
+    float gammaC[SEA16_NGAM][kSpecPad]; /* [c][i], rows 132 floats apart: the 25 lanes' float4 reads fall on different banks */
+    /* the analysis window and the digit-reversal places, staged once per launch */
+    float sigWindow[SEA16_NFFT];
+    unsigned short rev[SEA16_NFFT];
 };
 
-/* rfft (x, 512, 8) on L.work, elements already at their digit-reversed places */
-__device__ __forceinline__ void ns16_fft(float *x, const sea_ns16k_tables *t, int lane)
-{
-#pragma unroll 1
-    for (int pass = 0; pass < SEA16_FFT_PASSES; ++pass) {
-        const int cnt = (int)t->fftCount[pass];
-        const int n4 = (pass == 0) ? 0 : (1 << (pass - 1)), n8 = n4 >> 1; /* n2 = 2^(pass+1) */
-#pragma unroll 1
-        for (int r = lane; r < cnt; r += kLanes) {
-            const unsigned it = t->fftItem[pass][r];
-            const int kind = (int)(it >> 24), j = (int)((it >> 16) & 0xffu), i = (int)(it & 0xffffu);
-            if (kind == SEA16_BF_LEN2) { /* rfft.cpp:86-91 */
-                const float a0 = x[i], a1 = x[i + 1];
-                x[i] = a0 + a1;
-                x[i + 1] = a0 - a1;
-            } else if (kind == SEA16_BF_PLAIN) { /* :113-120 */
-                const int i1 = i, i3 = i + 2 * n4, i4 = i + 3 * n4;
-                const float x1 = x[i1], x3 = x[i3], x4 = x[i4];
-                const float t1 = x4 + x3;
-                x[i4] = x4 - x3;
-                x[i3] = x1 - t1;
-                x[i1] = x1 + t1;
-            } else if (kind == SEA16_BF_PI4) { /* :122-133: the sums are divided by sqrt 2 in double */
-                const int i1 = i + n8, i2 = i1 + n4, i3 = i2 + n4, i4 = i3 + n4;
-                const float x1 = x[i1], x2 = x[i2], x3 = x[i3], x4 = x[i4];
-                const float t1 = (float)((double)(x3 + x4) / 1.41421356237309504880);
-                const float t2 = (float)((double)(x3 - x4) / 1.41421356237309504880);
-                x[i4] = x2 - t1;
-                x[i3] = -x2 - t1;
-                x[i2] = x1 - t2;
-                x[i1] = x1 + t2;
-            } else { /* :139-176 */
-                const float cc1 = t->fftTw[pass][j][0], ss1 = t->fftTw[pass][j][1], cc3 = t->fftTw[pass][j][2],
-                            ss3 = t->fftTw[pass][j][3];
-                const int i1 = i + j, i2 = i1 + n4, i3 = i2 + n4, i4 = i3 + n4;
-                const int i5 = i + n4 - j, i6 = i5 + n4, i7 = i6 + n4, i8 = i7 + n4;
-                const float x1 = x[i1], x2 = x[i2], x3 = x[i3], x4 = x[i4], x5 = x[i5], x6 = x[i6], x7 = x[i7], x8 = x[i8];
-                float t1 = x3 * cc1 + x7 * ss1;
-                float t2 = x7 * cc1 - x3 * ss1;
-                float t3 = x4 * cc3 + x8 * ss3;
-                float t4 = x8 * cc3 - x4 * ss3;
-                const float t5 = t1 + t3, t6 = t2 + t4;
-                t3 = t1 - t3;
-                t4 = t2 - t4;
-                x[i3] = t6 - x6;
-                x[i8] = x6 + t6;
-                x[i7] = -x2 - t3;
-                x[i4] = x2 - t3;
-                x[i6] = x1 - t5;
-                x[i1] = x1 + t5;
-                x[i5] = x5 - t4;
-                x[i2] = x5 + t4;
-            }
-        }
-        wave_sync(); /* the butterflies of one pass touch disjoint elements; passes are ordered */
+/* rfft (x, 512, 8) on L.work, elements already at their digit-reversed places.  A pass = up to three butterflies per
+ * lane, one per slot, the kind of each slot fixed by the pass (sea_tables.h): straight-line code -- every lane reads the
+ * operands of all its slots (an empty slot reads element 0 and discards), computes, and only the stores are predicated --
+ * so the LDS round trips of the three butterflies overlap.  Butterflies of one pass touch disjoint elements. */
+struct Ns16Fft { /* a lane's share of the schedule, loaded once per launch: its butterflies and their twiddles */
+    unsigned slot[SEA16_FFT_PASSES][SEA16_FFT_SLOTS];
+    float4 tw[SEA16_FFT_PASSES]; /* cc1, ss1, cc3, ss3 of the twiddled butterfly of passes 3..7 */
+};
+__device__ __forceinline__ void bf_len2(float *x, unsigned it)
+{ /* rfft.cpp:86-91 */
+    const int i = (int)(it & 0xffffu);
+    const float a0 = x[i], a1 = x[i + 1];
+    const float s0 = a0 + a1, s1 = a0 - a1;
+    if (it >> 31) {
+        x[i] = s0;
+        x[i + 1] = s1;
     }
+}
+template <int N4>
+__device__ __forceinline__ void bf_plain(float *x, unsigned it)
+{ /* :113-120 */
+    const int i1 = (int)(it & 0xffffu), i3 = i1 + 2 * N4, i4 = i1 + 3 * N4;
+    const float x1 = x[i1], x3 = x[i3], x4 = x[i4];
+    const float t1 = x4 + x3;
+    const float r4 = x4 - x3, r3 = x1 - t1, r1 = x1 + t1;
+    if (it >> 31) {
+        x[i4] = r4;
+        x[i3] = r3;
+        x[i1] = r1;
+    }
+}
+template <int N4>
+__device__ __forceinline__ void bf_pi4(float *x, unsigned it)
+{ /* :122-133: the sums are divided by sqrt 2 in double */
+    const int i1 = (int)(it & 0xffffu) + N4 / 2, i2 = i1 + N4, i3 = i2 + N4, i4 = i3 + N4;
+    const float x1 = x[i1], x2 = x[i2], x3 = x[i3], x4 = x[i4];
+    /* == (float)((double)s / M_SQRT2) for every float s (sea_selftest_pi4 sweeps all 2^32) */
+    const float t1 = (float)((double)(x3 + x4) * 0.70710678118654752440);
+    const float t2 = (float)((double)(x3 - x4) * 0.70710678118654752440);
+    const float r4 = x2 - t1, r3 = -x2 - t1, r2 = x1 - t2, r1 = x1 + t2;
+    if (it >> 31) {
+        x[i4] = r4;
+        x[i3] = r3;
+        x[i2] = r2;
+        x[i1] = r1;
+    }
+}
+template <int N4>
+__device__ __forceinline__ void bf_twiddle(float *x, unsigned it, const float4 w)
+{ /* :139-176 */
+    const int i = (int)(it & 0xffffu), j = (int)((it >> 16) & 0xffu);
+    const float cc1 = w.x, ss1 = w.y, cc3 = w.z, ss3 = w.w;
+    const int i1 = i + j, i2 = i1 + N4, i3 = i2 + N4, i4 = i3 + N4;
+    const int i5 = i + N4 - j, i6 = i5 + N4, i7 = i6 + N4, i8 = i7 + N4;
+    const float x1 = x[i1], x2 = x[i2], x3 = x[i3], x4 = x[i4], x5 = x[i5], x6 = x[i6], x7 = x[i7], x8 = x[i8];
+    float t1 = x3 * cc1 + x7 * ss1;
+    float t2 = x7 * cc1 - x3 * ss1;
+    float t3 = x4 * cc3 + x8 * ss3;
+    float t4 = x8 * cc3 - x4 * ss3;
+    const float t5 = t1 + t3, t6 = t2 + t4;
+    t3 = t1 - t3;
+    t4 = t2 - t4;
+    const float r3 = t6 - x6, r8 = x6 + t6, r7 = -x2 - t3, r4 = x2 - t3, r6 = x1 - t5, r1 = x1 + t5, r5 = x5 - t4, r2 = x5 + t4;
+    if (it >> 31) {
+        x[i3] = r3;
+        x[i8] = r8;
+        x[i7] = r7;
+        x[i4] = r4;
+        x[i6] = r6;
+        x[i1] = r1;
+        x[i5] = r5;
+        x[i2] = r2;
+    }
+}
+
+template <int PASS>
+__device__ __forceinline__ void ns16_fft_pass(float *x, const Ns16Fft &t)
+{
+    constexpr int N4 = (PASS == 0) ? 0 : (1 << (PASS - 1)); /* n2 = 2^(PASS+1) */
+    const unsigned it0 = t.slot[PASS][0], it1 = t.slot[PASS][1];
+    if constexpr (PASS == 0) {
+        const unsigned it2 = t.slot[PASS][2];
+        /* the three length-2 butterflies of a lane touch disjoint pairs: all reads first */
+        const int i0 = (int)(it0 & 0xffffu), i1 = (int)(it1 & 0xffffu), i2 = (int)(it2 & 0xffffu);
+        const float a0 = x[i0], a1 = x[i0 + 1], b0 = x[i1], b1 = x[i1 + 1], c0 = x[i2], c1 = x[i2 + 1];
+        if (it0 >> 31) {
+            x[i0] = a0 + a1;
+            x[i0 + 1] = a0 - a1;
+        }
+        if (it1 >> 31) {
+            x[i1] = b0 + b1;
+            x[i1 + 1] = b0 - b1;
+        }
+        if (it2 >> 31) {
+            x[i2] = c0 + c1;
+            x[i2 + 1] = c0 - c1;
+        }
+    } else if constexpr (PASS == 1) {
+        bf_plain<N4>(x, it0);
+        bf_plain<N4>(x, it1);
+    } else {
+        bf_plain<N4>(x, it0);
+        bf_pi4<N4>(x, it1);
+        if constexpr (PASS >= 3) bf_twiddle<N4>(x, t.slot[PASS][2], t.tw[PASS]);
+    }
+    wave_sync(); /* passes are ordered */
+}
+
+__device__ __forceinline__ void ns16_fft(float *x, const Ns16Fft &t)
+{
+    ns16_fft_pass<0>(x, t);
+    ns16_fft_pass<1>(x, t);
+    ns16_fft_pass<2>(x, t);
+    ns16_fft_pass<3>(x, t);
+    ns16_fft_pass<4>(x, t);
+    ns16_fft_pass<5>(x, t);
+    ns16_fft_pass<6>(x, t);
+    ns16_fft_pass<7>(x, t);
 }
 
 /* DCOffsetFil over one 160-sample frame (NoiseSup.cpp:168-184) in the float-FMA form of ns_core.h's dc_filter: the
@@ -100,6 +184,33 @@ __device__ __forceinline__ void ns16_dc(const float *dif, float *out, float &ySt
 {
     const float y0 = yState;
     float y = y0;
+#if SEA16_PIPE_DC
+    constexpr int kQ = 8, kChunks = kHop / 4 / kQ;
+    float4 d[2][kQ];
+    auto request = [&](int c, float4(&dst)[kQ]) {
+#pragma unroll
+        for (int k = 0; k < kQ; ++k) dst[k] = *reinterpret_cast<const float4 *>(&dif[4 * (c * kQ + k)]);
+    };
+    request(0, d[0]);
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+        if (c + 1 < kChunks) request(c + 1, d[(c + 1) & 1]);
+#pragma unroll
+        for (int k = 0; k < kQ; ++k) {
+            float4 o;
+            y = __fmaf_rn(0.9990234375f, y, d[c & 1][k].x);
+            o.x = y;
+            y = __fmaf_rn(0.9990234375f, y, d[c & 1][k].y);
+            o.y = y;
+            y = __fmaf_rn(0.9990234375f, y, d[c & 1][k].z);
+            o.z = y;
+            y = __fmaf_rn(0.9990234375f, y, d[c & 1][k].w);
+            o.w = y;
+            *reinterpret_cast<float4 *>(&out[4 * (c * kQ + k)]) = o;
+        }
+        if (c + 1 < kChunks) __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll 4
     for (int n = 0; n < kHop; n += 4) {
         const float4 d = *reinterpret_cast<const float4 *>(&dif[n]);
@@ -114,6 +225,7 @@ __device__ __forceinline__ void ns16_dc(const float *dif, float *out, float &ySt
         o.w = y;
         *reinterpret_cast<float4 *>(&out[n]) = o;
     }
+#endif
     wave_sync();
     bool unsafe = false;
 #pragma unroll
@@ -133,21 +245,67 @@ __device__ __forceinline__ void ns16_dc(const float *dif, float *out, float &ySt
     wave_sync();
 }
 
+/* The two in-order sums of squares a frame starts with, advanced together, one per lane:
+ *   lane 0  the frame gate's FrameCheck = 0 + sum in[i]^2 (:1160-1164)          over sq[0..159]
+ *   lane 1  the VAD's frameEn = 64 + sum cur[i]^2 of the first stage (:373-376)   over sq2[0..159]
+ * (a wave issues a dependent add every ~8 clk whatever the number of active lanes) */
+__device__ __forceinline__ void ns16_frame_sums(const float *sq, const float *sq2, int lane, float &check, float &vadSum)
+{
+    const float *src = (lane == 1) ? sq2 : sq;
+    float acc = (lane == 1) ? 64.0f : 0.0f;
+#if SEA16_PIPE_SUMS
+    /* chunks of 8 quads, chunk c + 1 requested before the chain of chunk c starts (an LDS round trip is ~100 clk) */
+    constexpr int kQ = 8, kChunks = kHop / 4 / kQ;
+    float4 v[2][kQ];
+    auto request = [&](int c, float4(&dst)[kQ]) {
+#pragma unroll
+        for (int k = 0; k < kQ; ++k) dst[k] = *reinterpret_cast<const float4 *>(src + 4 * (c * kQ + k));
+    };
+    request(0, v[0]);
+#pragma unroll
+    for (int c = 0; c < kChunks; ++c) {
+        if (c + 1 < kChunks) request(c + 1, v[(c + 1) & 1]);
+#pragma unroll
+        for (int k = 0; k < kQ; ++k) {
+            acc += v[c & 1][k].x;
+            acc += v[c & 1][k].y;
+            acc += v[c & 1][k].z;
+            acc += v[c & 1][k].w;
+        }
+        if (c + 1 < kChunks) __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+#pragma unroll 8
+    for (int q = 0; q < kHop / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + 4 * q);
+        acc += v.x;
+        acc += v.y;
+        acc += v.z;
+        acc += v.w;
+    }
+#endif
+    check = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
+    vadSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 1));
+}
+
 /* one stage of one frame (:1207-1366) */
 template <int ST>
-__device__ __forceinline__ void ns16_stage(Ns16Lds &L, NsRegs &s, NsFd &fd, const sea_ns16k_tables *t, const float (&idct)[SEA16_NGAM],
-                                           float irWin, int lane, int &fdBits, float *wienerRow)
+__device__ __forceinline__ void ns16_stage(Ns16Lds &L, NsRegs &s, NsFd &fd, const Ns16Fft &fft, float eps, const float (&idct)[SEA16_NGAM],
+                                           float irWin, int lane, int &fdBits, float &gainOut, float vadSum)
 {
+    CK16_START;
     float *buf = L.buf[ST];
     /* window + zero padding (:209-222) straight to the digit-reversed places */
 #pragma unroll
     for (int k = 0; k < SEA16_NFFT / kLanes; ++k) {
         const int i = lane + kLanes * k;
-        const float v = (i < SEA16_WIN) ? buf[SEA16_AWIN + i] * t->sigWindow[i] : 0.0f;
-        L.work[t->rev[i]] = v;
+        const float v = (i < SEA16_WIN) ? buf[SEA16_AWIN + i] * L.sigWindow[i] : 0.0f;
+        L.work[L.rev[i]] = v;
     }
     wave_sync();
-    ns16_fft(L.work, t, lane);
+    CK16(ST * 10 + 0);
+    ns16_fft(L.work, fft);
+    CK16(ST * 10 + 1);
 
     /* FFTtoPSD (:240-261), PSDMean (:280-294) and FilterCalc (:440-553) per spectral value: b = lane, lane + 64, 128 */
     {
@@ -155,25 +313,17 @@ __device__ __forceinline__ void ns16_stage(Ns16Lds &L, NsRegs &s, NsFd &fd, cons
         if (nb < 2147483647) nb++;
         s.nbFrame[ST] = nb;
     }
-    if (ST == 0) { /* _VAD_ (:350-421) on curFrame = buf[160..319] */
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int i = lane + kLanes * k;
-            if (i < kHop) {
-                const float x = buf[kHop + i];
-                L.sq[i] = x * x;
-            }
-        }
-        wave_sync();
-        vad_update(s, vad_frame_energy(serial_sum<kHop>(L.sq, 64.0f)));
-    }
+    if (ST == 0) vad_update(s, vad_frame_energy(vadSum)); /* _VAD_ (:350-421); the frame sum comes from ns16_frame_sums */
+    CK16(ST * 10 + 2);
     const int nb16 = (int)(short)s.nbFrame[ST];
     const float *x = L.work;
+    /* b = lane, lane + 64, 128: the three values of a lane are independent chains */
+    float nSigv[3], Pv[3], noisev[3], denv[3], Wv[3];
+    bool inDomain = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int b = lane + kLanes * k;
-        const bool act = b < kSpec;
-        const int bb = act ? b : (kSpec - 1);
+        const int bb = (b < kSpec) ? b : (kSpec - 1);
         float nSig;
         if (bb == kSpec - 1) {
             nSig = x[256] * x[256];
@@ -183,48 +333,80 @@ __device__ __forceinline__ void ns16_stage(Ns16Lds &L, NsRegs &s, NsFd &fd, cons
             const float p1 = x[j1] * x[j1] + x[SEA16_NFFT - j1] * x[SEA16_NFFT - j1];
             nSig = (float)((double)(p0 + p1) / 2.0);
         }
-        const float P = (L.bins[4 + ST][bb] + nSig) / 2.0f;
-        float noise = L.bins[ST][bb], den = L.bins[2 + ST][bb];
-        const float W = filter_bin<ST, false>(P, nSig, noise, den, nb16, s.flagVAD, t->eps);
-        if (act) {
-            L.bins[4 + ST][b] = nSig;
-            L.bins[ST][b] = noise;
-            L.bins[2 + ST][b] = den;
-            L.W[b] = W;
+        nSigv[k] = nSig;
+        Pv[k] = (L.bins[4 + ST][bb] + nSig) / 2.0f;
+        noisev[k] = L.bins[ST][bb];
+        denv[k] = L.bins[2 + ST][bb];
+        inDomain &= ns_psd_in_domain(nSig) && noisev[k] <= 0x1p28f && noisev[k] >= 0x1p-15f;
+    }
+    /* the guarded fast-division domain of ns_core.h (ns_back): this frame's and the previous frame's spectral values
+     * in {0} u [2^-40, 2^48], the noise magnitudes in [2^-15, 2^28]; otherwise IEEE division and sqrtf throughout */
+    const bool domainNow = __ballot(!inDomain) == 0ull;
+    const bool fast = SEA_NS_FAST_DIV && domainNow && (s.psdOk[ST] != 0);
+    s.psdOk[ST] = domainNow ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        Wv[k] = fast ? filter_bin<ST, true>(Pv[k], nSigv[k], noisev[k], denv[k], nb16, s.flagVAD, eps)
+                     : filter_bin<ST, false>(Pv[k], nSigv[k], noisev[k], denv[k], nb16, s.flagVAD, eps);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int b = lane + kLanes * k;
+        if (b < kSpec) {
+            L.bins[4 + ST][b] = nSigv[k];
+            L.bins[ST][b] = noisev[k];
+            L.bins[2 + ST][b] = denv[k];
+            L.W[b] = Wv[k];
         }
     }
     wave_sync();
-    if (ST == 0) fdBits = fd_var<SEA16_NFFT / 4>(fd, L.W, nb16); /* SpeechQVar (:852-893) on the first 128 gains */
-
-    /* DoGamma (MelProc.cpp:119-135): window c = lane over gains 0..127, in order */
+    CK16(ST * 10 + 3);
+    CK16(ST * 10 + 4);
+    /* DoGamma (MelProc.cpp:119-135): window c = lane < 25 over gains 0..127, in order.  Three plain in-order sums ride
+     * along in lanes 25..27 as "windows" of their own -- same multiply-by-coefficient-then-add per step, x * 1.0f == x:
+     *   lane 25  mean = sum W[i]          (SpeechQVar, :866-870)     coefficients 1
+     *   lane 26  var  = sum W[i] * W[i]                               coefficients W itself
+     *   lane 27  sum of denSigSE1 (first stage) / noiseSE2 (second): DoGainFact_IBM (:648, :653), 129 terms */
+    float sum = 0.0f;
     {
-        float sum = 0.0f;
-        const int c = (lane < SEA16_NGAM) ? lane : 0;
+        const float *src = (lane == 27) ? L.bins[ST == 0 ? 2 : 1] : L.W;
+        const float *coef = (lane < SEA16_NGAM) ? L.gammaC[lane] : ((lane == 26) ? L.W : L.ones);
 #pragma unroll 8
-        for (int i = 0; i < SEA16_GLEN; ++i) sum += L.W[i] * L.gammaT[i][c];
-        wave_sync(); /* all 128 gains read before the outputs overwrite nothing here: gam is its own array */
+        for (int q = 0; q < SEA16_GLEN / 4; ++q) {
+            const float4 w = *reinterpret_cast<const float4 *>(src + 4 * q);
+            const float4 c = *reinterpret_cast<const float4 *>(coef + 4 * q);
+            sum += w.x * c.x;
+            sum += w.y * c.y;
+            sum += w.z * c.z;
+            sum += w.w * c.w;
+        }
+        if (lane == 27) sum += src[SEA16_GLEN]; /* the 129th spectral value */
         if (lane < SEA16_NGAM) L.gam[lane] = sum;
     }
     wave_sync();
-    if (ST == 0) { /* :1301-1311, :1362-1365 */
+    CK16(ST * 10 + 5);
+    const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), 27));
+    if (ST == 0) { /* SpeechQVar on the first 128 gains (:852-893), then :1301-1311, :1362-1365 */
+        const float mean = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), 25));
+        const float var = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sum), 26));
+        fdBits = fd_var_sums<SEA16_NFFT / 4>(fd, mean, var, nb16);
         fdBits |= fd_spec_mel(fd, L.gam, nb16) << 1;
         fdBits |= (s.nbSpeech > 4) ? 8 : 0;
     }
     /* DoGainFact_IBM (:634-698) */
     float g = L.gam[(lane < SEA16_NGAM) ? lane : 0];
     if (ST == 0) {
-        const float total = serial_sum<kSpec>(L.bins[2], 0.0f);
         s.denEn0 = s.denEn1;
         s.denEn1 = s.denEn2;
         s.denEn2 = total;
     } else {
-        gain_fact_update(s, serial_sum<kSpec>(L.bins[1], 0.0f));
+        gain_fact_update(s, total);
         g = (float)((double)(s.alfaGF * g) + (1.0 - (double)s.alfaGF) * 1.0);
-        if (wienerRow && lane < SEA16_NGAM) wienerRow[lane] = g; /* the line func_Wiener prints (:1319-1328) */
+        gainOut = g;
         wave_sync();
         if (lane < SEA16_NGAM) L.gam[lane] = g;
         wave_sync();
     }
+    CK16(ST * 10 + 6);
     /* DoGammaIDCT (MelProc.cpp:556-576), taps t = lane = 0..8, + DoFilterWindowing (:716-725) */
     {
         float h = 0.0f;
@@ -237,20 +419,29 @@ __device__ __forceinline__ void ns16_stage(Ns16Lds &L, NsRegs &s, NsFd &fd, cons
         }
     }
     wave_sync();
+    CK16(ST * 10 + 7);
     /* ApplyWF (cur, prv, filterIR, out, 160, 8) (:317-331): predata[160 - j + i] is cur[i - j] in the contiguous stage
      * buffer, so both loops are one sum over j = -8..8 in that order */
     float *dst = (ST == 0) ? (L.buf[1] + kIn) : L.outb;
+    {
+        float acc[3] = {0.0f, 0.0f, 0.0f}; /* the three outputs of a lane are independent chains: interleaved */
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int i = lane + kLanes * k;
-        if (i < kHop) {
-            float acc = 0.0f;
+        for (int j = -8; j <= 8; ++j) {
+            const float fj = L.fir[j + 8];
 #pragma unroll
-            for (int j = -8; j <= 8; ++j) acc += L.fir[j + 8] * buf[kHop + i - j];
-            dst[i] = acc;
+            for (int k = 0; k < 3; ++k) {
+                const int i = lane + kLanes * k;
+                acc[k] += fj * buf[kHop + ((i < kHop) ? i : 0) - j];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = lane + kLanes * k;
+            if (i < kHop) dst[i] = acc[k];
         }
     }
     wave_sync();
+    CK16(ST * 10 + 8);
 }
 
 /* slide a stage buffer by one hop (:1372-1390) */
@@ -284,7 +475,20 @@ __global__ void __launch_bounds__(64) ns16k_stream_kernel(Ns16StreamArgs a)
     NsFd fd;
     float *blob = a.state + (size_t)b * kNs16StateFloats;
 
-    for (int i = lane; i < SEA16_GLEN * SEA16_NGAM; i += kLanes) (&L.gammaT[0][0])[i] = (&t->gammaT[0][0])[i];
+    for (int i = lane; i < SEA16_GLEN * SEA16_NGAM; i += kLanes) L.gammaC[i % SEA16_NGAM][i / SEA16_NGAM] = (&t->gammaT[0][0])[i];
+    for (int i = lane; i < kSpecPad; i += kLanes) L.ones[i] = 1.0f;
+    Ns16Fft fft;
+#pragma unroll
+    for (int p = 0; p < SEA16_FFT_PASSES; ++p) {
+#pragma unroll
+        for (int k = 0; k < SEA16_FFT_SLOTS; ++k) fft.slot[p][k] = t->fftSlot[p][k][lane];
+        fft.tw[p] = *reinterpret_cast<const float4 *>(t->fftTw[p][(fft.slot[p][2] >> 16) & 0xffu]);
+    }
+    for (int i = lane; i < SEA16_NFFT; i += kLanes) {
+        L.sigWindow[i] = t->sigWindow[i];
+        L.rev[i] = t->rev[i];
+    }
+    const float eps = t->eps;
     float idct[SEA16_NGAM];
 #pragma unroll
     for (int f = 0; f < SEA16_NGAM; ++f) idct[f] = t->idctT[f][lane & 15];
@@ -307,24 +511,44 @@ __global__ void __launch_bounds__(64) ns16k_stream_kernel(Ns16StreamArgs a)
         fd.mel0 = q[12]; fd.specValues = q[13]; fd.speechInVADQ = q[14];
         s.nbFrame[0] = qi[0]; s.nbFrame[1] = qi[1]; s.flagVAD = qi[2]; s.hangOver = qi[3];
         s.nbSpeech = qi[4]; s.nIn1 = qi[5]; s.nIn2 = qi[6]; s.nOut2 = qi[7];
+        s.psdOk[0] = qi[10] & 1; s.psdOk[1] = (qi[10] >> 1) & 1;
     }
     wave_sync();
 
     const float *in = a.in + (size_t)b * a.nframes * kHop;
     float *out = a.out + (size_t)b * a.nframes * kHop;
+    float xin[3], xnext[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = lane + kLanes * k;
+        xin[k] = (i < kHop && a.nframes > 0) ? in[i] : 0.0f;
+    }
     for (int f = 0; f < a.nframes; ++f, in += kHop, out += kHop) {
         const size_t rec = (size_t)b * a.nframes + f;
-        /* the frame gate (:1160-1171): float sum of squares in sample order, truncated to int */
-        float xin[3];
+        CK16_START;
+        /* the next frame's samples are requested now and first touched at the end of this frame, just before this
+         * frame's stores are issued: a wait for them is then a wait for nothing else */
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int i = lane + kLanes * k;
-            xin[k] = (i < kHop) ? in[i] : 0.0f;
-            if (i < kHop) L.sq[i] = xin[k] * xin[k];
+            xnext[k] = (i < kHop && f + 1 < a.nframes) ? in[kHop + i] : 0.0f;
+        }
+        /* the frame gate (:1160-1171): float sum of squares in sample order, truncated to int */
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = lane + kLanes * k;
+            if (i < kHop) {
+                L.sq[i] = xin[k] * xin[k];
+                const float c = L.buf[0][kHop + i];
+                L.sq2[i] = c * c;
+            }
         }
         wave_sync();
-        const float check = uniform_f(serial_sum<kHop>(L.sq, 0.0f));
+        float check, vadSum;
+        ns16_frame_sums(L.sq, L.sq2, lane, check, vadSum);
         int produced = 0, counter = 0, fdBits = 0;
+        float gain = 0.0f; /* lane c < 25: the c-th of the gains func_Wiener prints for this frame */
+        CK16(20);
         if (!(check < 1.0f)) { /* (int)check != 0; NaN and overflow convert to INT_MIN on the reference's x86 */
             wave_sync();
 #pragma unroll
@@ -335,19 +559,24 @@ __global__ void __launch_bounds__(64) ns16k_stream_kernel(Ns16StreamArgs a)
             wave_sync();
             s.nIn1++;
             if (s.nIn1 - s.nIn2 > 2) { /* :1212 */
-                ns16_stage<0>(L, s, fd, t, idct, irWin, lane, fdBits, nullptr);
+                float unused;
+                ns16_stage<0>(L, s, fd, fft, eps, idct, irWin, lane, fdBits, unused, vadSum);
                 s.nIn2++;
                 counter = s.nbFrame[0];
             }
             if (s.nIn2 - s.nOut2 > 2) { /* :1230 */
                 int unused = 0;
-                ns16_stage<1>(L, s, fd, t, idct, irWin, lane, unused, a.wiener ? a.wiener + rec * SEA16_NGAM : nullptr);
+                ns16_stage<1>(L, s, fd, fft, eps, idct, irWin, lane, unused, gain, 0.0f);
                 s.nOut2++;
                 produced = 1;
             }
+#ifdef SEA16_TIMING
+            ck_ = clock64();
+#endif
             ns16_slide(L.buf[0], lane);
             if (s.nIn2) ns16_slide(L.buf[1], lane);
             wave_sync();
+            CK16(21);
             if (s.nOut2 > 0) { /* DCOffsetFil on the frame just written (:1392-1395) */
                 float d[3];
 #pragma unroll
@@ -364,12 +593,19 @@ __global__ void __launch_bounds__(64) ns16k_stream_kernel(Ns16StreamArgs a)
                 }
                 wave_sync();
                 ns16_dc(L.sq, L.outb, s.dcY, lane);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int i = lane + kLanes * k;
-                    if (i < kHop) out[i] = L.outb[i];
-                }
+                CK16(22);
             }
+        }
+        asm volatile("" : "+v"(xnext[0]), "+v"(xnext[1]), "+v"(xnext[2])); /* the wait for the next frame's samples sits here */
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xin[k] = xnext[k];
+        if (produced) { /* once the second stage runs it runs at every frame that passes the gate: nOut2 > 0 here */
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int i = lane + kLanes * k;
+                if (i < kHop) out[i] = L.outb[i];
+            }
+            if (a.wiener && lane < SEA16_NGAM) a.wiener[rec * SEA16_NGAM + lane] = gain; /* the line func_Wiener prints (:1319-1328) */
         }
         if (lane == 0) {
             a.produced[rec] = produced;
@@ -390,7 +626,19 @@ __global__ void __launch_bounds__(64) ns16k_stream_kernel(Ns16StreamArgs a)
         q[12] = fd.mel0; q[13] = fd.specValues; q[14] = fd.speechInVADQ;
         qi[0] = s.nbFrame[0]; qi[1] = s.nbFrame[1]; qi[2] = s.flagVAD; qi[3] = s.hangOver;
         qi[4] = s.nbSpeech; qi[5] = s.nIn1; qi[6] = s.nIn2; qi[7] = s.nOut2;
+        qi[10] = (s.psdOk[0] ? 1 : 0) | (s.psdOk[1] ? 2 : 0);
     }
 }
+
+#ifdef SEA16_TIMING
+extern "C" int sea_ns16k_timing(unsigned long long *out24, int reset)
+{
+    if (reset) {
+        unsigned long long z[24] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_ns16_ck), z, sizeof z) != hipSuccess;
+    }
+    return hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_ns16_ck), 24 * sizeof(unsigned long long)) != hipSuccess;
+}
+#endif
 
 } // namespace sea

@@ -663,7 +663,19 @@ struct NsFd {
 };
 __device__ __forceinline__ void fd_init(NsFd &d) { d.melMean = d.varMean = d.accTest = d.specMean = d.mel0 = d.specValues = d.speechInVADQ = 0.0f; }
 
-/* SpeechQVar: variance of the first N = NS_FFT_LENGTH / 4 Wiener gains W (in LDS), two in-order float sums */
+/* SpeechQVar given the two in-order sums over the first N = NS_FFT_LENGTH / 4 Wiener gains (mean = sum W, var = sum W^2) */
+template <int N>
+__device__ __forceinline__ int fd_var_sums(NsFd &d, float mean, float var, int fc)
+{
+    const float specVar = (var / (float)N) - mean * mean / (float)(N * N);
+    if (fc < 15) d.varMean = (d.varMean > specVar) ? d.varMean : specVar;
+    if ((double)specVar < (double)d.varMean * 1.5 && (double)specVar > (double)d.varMean * 0.85)
+        d.varMean = (float)((double)d.varMean * 0.8 + (double)specVar * 0.2);
+    if ((double)specVar <= (double)d.varMean * 0.25) d.varMean = (float)((double)d.varMean * 0.97 + (double)specVar * 0.03);
+    return ((double)specVar > (double)d.varMean * 1.65) ? 1 : 0;
+}
+
+/* SpeechQVar: variance of the first N Wiener gains W (in LDS), two in-order float sums */
 template <int N = 64>
 __device__ __forceinline__ int fd_var(NsFd &d, const float *W, int fc)
 {
@@ -676,14 +688,7 @@ __device__ __forceinline__ int fd_var(NsFd &d, const float *W, int fc)
         mean += w.z; var += w.z * w.z;
         mean += w.w; var += w.w * w.w;
     }
-    mean = uniform_f(mean);
-    var = uniform_f(var);
-    const float specVar = (var / (float)N) - mean * mean / (float)(N * N);
-    if (fc < 15) d.varMean = (d.varMean > specVar) ? d.varMean : specVar;
-    if ((double)specVar < (double)d.varMean * 1.5 && (double)specVar > (double)d.varMean * 0.85)
-        d.varMean = (float)((double)d.varMean * 0.8 + (double)specVar * 0.2);
-    if ((double)specVar <= (double)d.varMean * 0.25) d.varMean = (float)((double)d.varMean * 0.97 + (double)specVar * 0.03);
-    return ((double)specVar > (double)d.varMean * 1.65) ? 1 : 0;
+    return fd_var_sums<N>(d, uniform_f(mean), uniform_f(var), fc);
 }
 
 /* SpeechQSpec + SpeechQMel on the 25 mel-filtered gains (in LDS); returns spec | mel << 1 */

@@ -496,27 +496,30 @@ static void gamma_idct(const int start[SEA16_NGAM], float basis[SEA16_NGAM][SEA1
 typedef struct {
     sea_ns16k_tables *t;
     int pass, n8, kind;
+    int count[4]; /* per kind, this pass */
 } item_ctx;
+static void slot_put(item_ctx *c, int kind, unsigned entry)
+{
+    /* pass 0: LEN2 fills slots 0, 1, 2; pass 1: PLAIN fills slots 0, 1; later passes: one slot per kind */
+    const int n = c->count[kind]++;
+    int slot, lane = n & 63;
+    if (c->pass == 0) slot = n >> 6;
+    else if (c->pass == 1) slot = n >> 6;
+    else slot = (kind == SEA16_BF_PLAIN ? 0 : kind == SEA16_BF_PI4 ? 1 : 2) + 3 * (n >> 6); /* >= 3: does not fit */
+    if (slot >= SEA16_FFT_SLOTS || (c->pass == 1 && (kind != SEA16_BF_PLAIN || slot > 1))) abort();
+    c->t->fftSlot[c->pass][slot][lane] = 0x80000000u | entry;
+}
 static void item_visit(int i, void *ctx)
 {
     item_ctx *c = (item_ctx *)ctx;
-    unsigned *cnt = &c->t->fftCount[c->pass];
     int j;
     if (c->kind == SEA16_BF_LEN2) {
-        if (*cnt < SEA16_FFT_ITEMS) c->t->fftItem[c->pass][*cnt] = ((unsigned)SEA16_BF_LEN2 << 24) | (unsigned)i;
-        ++*cnt;
+        slot_put(c, SEA16_BF_LEN2, (unsigned)i);
         return;
     }
-    if (*cnt < SEA16_FFT_ITEMS) c->t->fftItem[c->pass][*cnt] = ((unsigned)SEA16_BF_PLAIN << 24) | (unsigned)i;
-    ++*cnt;
-    if (c->n8 >= 1) { /* n4 != 1 */
-        if (*cnt < SEA16_FFT_ITEMS) c->t->fftItem[c->pass][*cnt] = ((unsigned)SEA16_BF_PI4 << 24) | (unsigned)i;
-        ++*cnt;
-    }
-    for (j = 1; j < c->n8; j++) {
-        if (*cnt < SEA16_FFT_ITEMS) c->t->fftItem[c->pass][*cnt] = ((unsigned)SEA16_BF_TWIDDLE << 24) | ((unsigned)j << 16) | (unsigned)i;
-        ++*cnt;
-    }
+    slot_put(c, SEA16_BF_PLAIN, (unsigned)i);
+    if (c->n8 >= 1) slot_put(c, SEA16_BF_PI4, (unsigned)i); /* n4 != 1 */
+    for (j = 1; j < c->n8; j++) slot_put(c, SEA16_BF_TWIDDLE, ((unsigned)j << 16) | (unsigned)i);
 }
 
 void sea_build_ns16k_tables(sea_ns16k_tables *t)
@@ -557,6 +560,7 @@ void sea_build_ns16k_tables(sea_ns16k_tables *t)
         for (i = 0; i < SEA16_NFFT; i++) t->rev[pos[i]] = (unsigned short)i;
     }
     /* pass 0: length-2 butterflies (:82-96); passes 1..7: levels n2 = 4..256 (:99-179 with m = 8) */
+    memset(&ctx, 0, sizeof ctx);
     ctx.t = t;
     ctx.pass = 0;
     ctx.kind = SEA16_BF_LEN2;
@@ -575,6 +579,7 @@ void sea_build_ns16k_tables(sea_ns16k_tables *t)
         ctx.pass = k;
         ctx.kind = SEA16_BF_PLAIN;
         ctx.n8 = n2 >> 3;
+        memset(ctx.count, 0, sizeof ctx.count);
         for_each_block(SEA16_NFFT, n2, 0, item_visit, &ctx);
         e = (float)((kPi * 2) / n2);
         for (j = 1; j < (n2 >> 3); j++) {
@@ -585,8 +590,6 @@ void sea_build_ns16k_tables(sea_ns16k_tables *t)
             t->fftTw[k][j][3] = sinf(a3);
         }
     }
-    for (k = 0; k < SEA16_FFT_PASSES; k++)
-        if (t->fftCount[k] > SEA16_FFT_ITEMS) abort(); /* the schedule no longer fits its table */
 }
 
 void sea_ns16k_plain_tables(float *sigWindow480, float *irWindow17, int *gammaStart25, float *gamma25x128, float *idct25x25)
@@ -617,9 +620,11 @@ void sea_ns16k_fft_host(float *x512)
     for (i = 0; i < SEA16_NFFT; i++) x[t.rev[i]] = x512[i];
     for (pass = 0; pass < SEA16_FFT_PASSES; pass++) {
         const int n4 = (pass == 0) ? 0 : (1 << (pass - 1)), n8 = n4 >> 1;
-        for (r = t.fftCount[pass]; r-- > 0;) { /* backwards: the order within a pass must not matter */
-            const unsigned it = t.fftItem[pass][r];
-            const int kind = (int)(it >> 24), j = (int)((it >> 16) & 0xffu);
+        for (r = SEA16_FFT_SLOTS * SEA_LANES; r-- > 0;) { /* backwards: the order within a pass must not matter */
+            const unsigned it = t.fftSlot[pass][r / SEA_LANES][r % SEA_LANES];
+            const int slot = (int)(r / SEA_LANES), j = (int)((it >> 16) & 0xffu);
+            const int kind = (pass == 0) ? SEA16_BF_LEN2 : (pass == 1) ? SEA16_BF_PLAIN : (slot == 0 ? SEA16_BF_PLAIN : slot == 1 ? SEA16_BF_PI4 : SEA16_BF_TWIDDLE);
+            if (!(it >> 31)) continue;
             i = (int)(it & 0xffffu);
             if (kind == SEA16_BF_LEN2) {
                 const float a0 = x[i], a1 = x[i + 1];

@@ -126,15 +126,18 @@ enum {
     SEA16_NGAM = 25,       /* WF_MEL_ORDER: gammatone-shaped windows */
     SEA16_GLEN = 128,      /* every window covers gains 0..127 (MelProc.cpp:298) */
     SEA16_FFT_PASSES = 8,  /* pass 0: the length-2 butterflies; pass k: the L-shaped level n2 = 2^(k+1) */
-    SEA16_FFT_ITEMS = 192  /* most butterflies of one pass (asserted at build) */
+    SEA16_FFT_SLOTS = 3    /* butterflies one lane runs per pass */
 };
+/* Slot s of pass p holds at most 64 butterflies of ONE kind, fixed per (p, s) so that the kernel's code per pass is
+ * straight-line:  pass 0: three slots of length-2 butterflies (171);  pass 1 (n2 = 4): two slots of plain butterflies
+ * (85; n4 = 1 has no pi/4 partner);  passes 2..7: slot 0 plain, slot 1 pi/4, slot 2 twiddled (none at n2 = 8).
+ * Entry: valid << 31 | j << 16 | block start i. */
 enum { SEA16_BF_LEN2 = 0, SEA16_BF_PLAIN = 1, SEA16_BF_PI4 = 2, SEA16_BF_TWIDDLE = 3 };
 
 typedef struct {
     float sigWindow[SEA16_NFFT];                          /* Hanning(480), 0 beyond */
     unsigned short rev[SEA16_NFFT];                       /* where rfft.cpp's digit-reverse counter puts input element i */
-    unsigned fftCount[SEA16_FFT_PASSES];
-    unsigned fftItem[SEA16_FFT_PASSES][SEA16_FFT_ITEMS];  /* kind << 24 | j << 16 | block start i */
+    unsigned fftSlot[SEA16_FFT_PASSES][SEA16_FFT_SLOTS][SEA_LANES];
     float fftTw[SEA16_FFT_PASSES][32][4];                 /* cc1, ss1, cc3, ss3 of twiddle index j at that pass */
     float gammaT[SEA16_GLEN][SEA16_NGAM];                 /* [i][c]: window c's weight of gain i */
     float idctT[SEA16_NGAM][16];                          /* [f][t], t = 0..8: the nine taps DoFilterWindowing reads */
