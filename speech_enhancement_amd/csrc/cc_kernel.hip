@@ -396,10 +396,19 @@ __global__ __launch_bounds__(64) void compceps_kernel(CepsArgs a)
  * ================================================================================================ */
 namespace {
 
-struct __attribute__((aligned(16))) WpLds { /* scratch of DoWaveProc for one frame */
+#ifndef SEA_WP_ROWS
+#define SEA_WP_ROWS 1 /* 1: the peak searches of four frames side by side, one per row of 16 lanes (feature pass 4.19 -> 3.82 ms);
+                         0: one frame at a time, wave-wide.  Dealing the Teager / smoothing / window steps of the four frames
+                         to the lanes as 800 samples as well (13 rounds, one sync per group) measured SLOWER, 4.39 ms: per-lane
+                         frame index, divisions by 200 and a divergent loop over each frame's own peak list */
+#endif
+
+struct __attribute__((aligned(16))) WpLds { /* scratch of DoWaveProc: four frames in flight */
     float tw[200];
-    int q[200], sm[200];
-    int pos[24];
+    int q[200];
+    int sm[4][200];
+    int pos[4][24];
+    int nom[4];
 };
 
 /* wave-wide maximum of a signed 32-bit value in 6 DPP steps (row_shr 1/2/4/8 within rows of 16
@@ -429,11 +438,34 @@ __device__ __forceinline__ int wave_argmax(int value, int index, bool valid, boo
     return lowWins ? 255 - c : c;
 }
 
-/* DoWaveProc (WaveProc.c:397-455) on d[0..199], in place, for a frame whose low-energy check (:423-427: in-order
- * sum of squares >= 100, evaluated by the caller lane = frame) has passed: Teager energy (:216-226), its 9-point
- * integer smoothing, maxima 25..79 samples apart (:102-190), a two-level window around them (:244-330).
- * Ends with wave_sync(). */
-__device__ __forceinline__ void waveproc_frame(WpLds &W, float *d, int lane)
+/* maximum over each ROW of 16 lanes, left in every lane of the row: an xor butterfly in four DPP steps
+ * (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) */
+__device__ __forceinline__ int row_max_i32(int v)
+{
+    auto mx = [](int a, int b) { return a > b ? a : b; };
+    v = mx(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    v = mx(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+    return v;
+}
+
+/* wave_argmax per row of 16 lanes (every lane of a row gets its row's answer) */
+__device__ __forceinline__ int row_argmax(int value, int index, bool valid, bool lowWins)
+{
+    const int m = row_max_i32(valid ? value : -1);
+    const int code = (valid && value == m) ? (lowWins ? 255 - index : index) : -1;
+    const int c = row_max_i32(code);
+    return (m < 0) ? -1 : (lowWins ? 255 - c : c);
+}
+
+/* DoWaveProc (WaveProc.c:397-455) on a frame d[0..199] whose low-energy check (:423-427: in-order sum of squares >= 100,
+ * evaluated by the caller lane = frame) has passed, in three steps:
+ *   wp_smooth   Teager energy (:216-226) and its 9-point integer smoothing                      -> W.sm[slot]
+ *   wp_peaks    maxima 25..79 samples apart (:102-190)                                          -> W.pos[slot], W.nom[slot]
+ *   wp_window   a two-level window around them (:244-330), applied in place
+ * Each ends with wave_sync(). */
+__device__ __forceinline__ void wp_smooth(WpLds &W, int slot, const float *d, int lane)
 {
     constexpr int N = 200;
     /* Teager energy and its integer quarter, (int)floor(T * 0.25 + 0.5) in double */
@@ -459,10 +491,17 @@ __device__ __forceinline__ void waveproc_frame(WpLds &W, float *d, int lane)
                 idx = idx < 0 ? 0 : (idx > N - 1 ? N - 1 : idx);
                 acc += (unsigned)W.q[idx];
             }
-            W.sm[i] = (int)acc;
+            W.sm[slot][i] = (int)acc;
         }
     }
     wave_sync();
+}
+
+/* one frame, wave-wide */
+__device__ __forceinline__ void wp_peaks(WpLds &W, int slot, int lane)
+{
+    constexpr int N = 200;
+    const int *sm = W.sm[slot];
     /* global maximum: first index of the largest value, which must exceed 0 */
     int nom = 0;
     {
@@ -470,8 +509,8 @@ __device__ __forceinline__ void waveproc_frame(WpLds &W, float *d, int lane)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = lane + 64 * k;
-            if (i < N && W.sm[i] > bv) { /* ascending i per lane: strict > keeps the first */
-                bv = W.sm[i];
+            if (i < N && sm[i] > bv) { /* ascending i per lane: strict > keeps the first */
+                bv = sm[i];
                 bi = i;
             }
         }
@@ -484,7 +523,7 @@ __device__ __forceinline__ void waveproc_frame(WpLds &W, float *d, int lane)
             while (R[cR] + 25 < N && found) { /* to the right: last of equals = the higher index */
                 const int idx = R[cR] + 25 + lane;
                 const bool in = lane < 55 && idx < N;
-                const int v = in ? W.sm[idx] : -1;
+                const int v = in ? sm[idx] : -1;
                 const int nx = wave_argmax(v, idx, in && v >= 0, false);
                 found = nx >= 0;
                 if (found) {
@@ -499,7 +538,7 @@ __device__ __forceinline__ void waveproc_frame(WpLds &W, float *d, int lane)
             while (Lf[cL] - 25 > 0 && found) { /* to the left: last of equals in scan order = the lower index */
                 const int idx = Lf[cL] - 25 - lane;
                 const bool in = lane < 55 && idx > -1;
-                const int v = in ? W.sm[idx] : -1;
+                const int v = in ? sm[idx] : -1;
                 const int nx = wave_argmax(v, idx, in && v >= 0, true);
                 found = nx >= 0;
                 if (found) {
@@ -513,15 +552,120 @@ __device__ __forceinline__ void waveproc_frame(WpLds &W, float *d, int lane)
             if (lane == 0) {
 #pragma unroll
                 for (int c = 9; c >= 1; --c)
-                    if (c <= cL) W.pos[nom++] = Lf[c];
+                    if (c <= cL) W.pos[slot][nom++] = Lf[c];
 #pragma unroll
                 for (int c = 0; c < 10; ++c)
-                    if (c <= cR) W.pos[nom++] = R[c];
+                    if (c <= cR) W.pos[slot][nom++] = R[c];
             }
             nom = cL + cR + 1;
         }
     }
+    if (lane == 0) W.nom[slot] = nom;
     wave_sync();
+}
+
+/* the same search for up to four frames at once, frame `slot` = row `slot` of 16 lanes (mask: bit slot = that frame takes
+ * part): the searches are short dependent chains of wave-wide reductions, so four of them side by side cost what one does */
+__device__ __forceinline__ void wp_peaks4(WpLds &W, unsigned mask, int lane)
+{
+    constexpr int N = 200;
+    const int row = lane >> 4, l = lane & 15;
+    const int *sm = W.sm[row];
+    const bool on = (mask >> row) & 1u;
+    int bv = 0, bi = -1;
+#pragma unroll
+    for (int k = 0; k < 13; ++k) {
+        const int i = l + 16 * k;
+        if (i < N) {
+            const int v = sm[i];
+            if (v > bv) { /* ascending i per lane: strict > keeps the first */
+                bv = v;
+                bi = i;
+            }
+        }
+    }
+    const int p0 = row_argmax(bv, bi, on && bi >= 0, true);
+    int nom = 0;
+    int R[10], Lf[10], cR = 0, cL = 0;
+    R[0] = Lf[0] = p0;
+    int cur = p0;
+    bool go = p0 >= 0 && cur + 25 < N;
+#pragma unroll 1
+    while (__ballot(go) != 0ull) { /* to the right: last of equals = the higher index */
+        int v = -1, vi = -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int off = l + 16 * k, idx = cur + 25 + off;
+            if (go && off < 55 && idx < N) {
+                const int x = sm[idx];
+                if (x >= v) { /* ascending idx per lane: >= keeps the last */
+                    v = x;
+                    vi = idx;
+                }
+            }
+        }
+        const int nx = row_argmax(v, vi, go && v >= 0, false);
+        if (go) {
+            if (nx >= 0) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c)
+                    if (c == cR) R[c + 1] = nx;
+                cR++;
+                cur = nx;
+                go = cur + 25 < N;
+            } else
+                go = false;
+        }
+    }
+    cur = p0;
+    go = p0 >= 0 && cur - 25 > 0;
+#pragma unroll 1
+    while (__ballot(go) != 0ull) { /* to the left: last of equals in scan order = the lower index */
+        int v = -1, vi = -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int off = l + 16 * k, idx = cur - 25 - off;
+            if (go && off < 55 && idx > -1) {
+                const int x = sm[idx];
+                if (x >= v) { /* descending idx per lane: >= keeps the lowest */
+                    v = x;
+                    vi = idx;
+                }
+            }
+        }
+        const int nx = row_argmax(v, vi, go && v >= 0, true);
+        if (go) {
+            if (nx >= 0) {
+#pragma unroll
+                for (int c = 0; c < 9; ++c)
+                    if (c == cL) Lf[c + 1] = nx;
+                cL++;
+                cur = nx;
+                go = cur - 25 > 0;
+            } else
+                go = false;
+        }
+    }
+    if (p0 >= 0) {
+        if (l == 0) { /* ascending: left ones (farthest first), centre, right ones */
+#pragma unroll
+            for (int c = 9; c >= 1; --c)
+                if (c <= cL) W.pos[row][nom++] = Lf[c];
+#pragma unroll
+            for (int c = 0; c < 10; ++c)
+                if (c <= cR) W.pos[row][nom++] = R[c];
+        }
+        nom = cL + cR + 1;
+    }
+    if (l == 0) W.nom[row] = nom;
+    wave_sync();
+}
+
+__device__ __forceinline__ void wp_window(WpLds &W, int slot, float *d, int lane)
+{
+    constexpr int N = 200;
+    const int nom = W.nom[slot];
+    const int *pos = W.pos[slot];
     const float eps = (float)0.2;
     const float lowVal = (float)((double)(1 - eps) / 2.0), highVal = (float)((double)(1 + eps) / 2.0);
 #pragma unroll
@@ -533,11 +677,11 @@ __device__ __forceinline__ void waveproc_frame(WpLds &W, float *d, int lane)
             bool high = false;
             if (nom > 1) {
                 int cnt = 0;
-                for (int i = 0; i < nom; ++i) cnt += (W.pos[i] - 4 <= j) ? 1 : 0;
+                for (int i = 0; i < nom; ++i) cnt += (pos[i] - 4 <= j) ? 1 : 0;
                 if (cnt > 0) {
                     const int i = cnt - 1;
-                    const int gap = (i < nom - 1) ? (W.pos[i + 1] - W.pos[i]) : (W.pos[nom - 1] - W.pos[nom - 2]);
-                    high = j < W.pos[i] - 4 + (80 * gap + 99) / 100;
+                    const int gap = (i < nom - 1) ? (pos[i + 1] - pos[i]) : (pos[nom - 1] - pos[nom - 2]);
+                    high = j < pos[i] - 4 + (80 * gap + 99) / 100;
                 }
             }
             W.tw[j] = high ? highVal : lowVal;
@@ -621,8 +765,24 @@ __global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
                 }
             }
             const unsigned long long pass = __ballot(lane < nv && (double)energy >= 100.0);
+#if SEA_WP_ROWS
+            for (int g = 0; g < nv; g += 4) { /* four frames at a time: their peak searches run side by side */
+                const unsigned m4 = (unsigned)(pass >> g) & 0xfu;
+                if (m4 == 0) continue;
+                for (int r = 0; r < 4; ++r)
+                    if ((m4 >> r) & 1u) wp_smooth(W, r, L.span + 201 * (g + r) + 1, lane);
+                wp_peaks4(W, m4, lane);
+                for (int r = 0; r < 4; ++r)
+                    if ((m4 >> r) & 1u) wp_window(W, r, L.span + 201 * (g + r) + 1, lane);
+            }
+#else
             for (int f = 0; f < nv; ++f)
-                if ((pass >> f) & 1ull) waveproc_frame(W, L.span + 201 * f + 1, lane);
+                if ((pass >> f) & 1ull) {
+                    wp_smooth(W, 0, L.span + 201 * f + 1, lane);
+                    wp_peaks(W, 0, lane);
+                    wp_window(W, 0, L.span + 201 * f + 1, lane);
+                }
+#endif
             wave_sync();
             cc_tile<false>(L, C, nv, dst, lane);
         }
