@@ -664,10 +664,16 @@ __device__ __forceinline__ void wp_peaks4(WpLds &W, unsigned mask, int lane)
 __device__ __forceinline__ void wp_window(WpLds &W, int slot, float *d, int lane)
 {
     constexpr int N = 200;
+    constexpr int kMaxPeaks = 12; /* maxima are at least 25 samples apart: at most 8 in 200 samples */
     const int nom = W.nom[slot];
     const int *pos = W.pos[slot];
     const float eps = (float)0.2;
     const float lowVal = (float)((double)(1 - eps) / 2.0), highVal = (float)((double)(1 + eps) / 2.0);
+    /* the peak list once into registers (one LDS round trip instead of one per peak and round); entries beyond the
+     * list sit past every sample */
+    int pk[kMaxPeaks];
+#pragma unroll
+    for (int c = 0; c < kMaxPeaks; ++c) pk[c] = (c < nom) ? pos[c] : (1 << 20);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int j = lane + 64 * k;
@@ -677,7 +683,8 @@ __device__ __forceinline__ void wp_window(WpLds &W, int slot, float *d, int lane
             bool high = false;
             if (nom > 1) {
                 int cnt = 0;
-                for (int i = 0; i < nom; ++i) cnt += (pos[i] - 4 <= j) ? 1 : 0;
+#pragma unroll
+                for (int c = 0; c < kMaxPeaks; ++c) cnt += (pk[c] - 4 <= j) ? 1 : 0;
                 if (cnt > 0) {
                     const int i = cnt - 1;
                     const int gap = (i < nom - 1) ? (pos[i + 1] - pos[i]) : (pos[nom - 1] - pos[nom - 2]);
