@@ -709,6 +709,24 @@ __device__ __forceinline__ void wp_window(WpLds &W, int slot, float *d, int lane
  * cepstral frames of one utterance as SEPARATE 201-float frames in LDS (WaveProc reshapes each frame in place, so
  * they cannot share samples).  The low-energy check's in-order sum of squares runs lane = frame; the frames that
  * pass go through DoWaveProc one after the other (wave-wide peak search), then the tile through cc_tile(). */
+/* timing-only diagnostic (-DSEA_AFE_TIMING, tools/afe_phases.py): shader clocks workgroup 0 spends per step of a tile */
+#ifdef SEA_AFE_TIMING
+__device__ unsigned long long g_afe_ck[8];
+extern "C" int sea_afe_timing(unsigned long long *out8, int reset)
+{
+    if (reset) {
+        unsigned long long z[8] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_afe_ck), z, sizeof z) != hipSuccess;
+    }
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_afe_ck), 8 * sizeof(unsigned long long)) != hipSuccess;
+}
+#define AFE_CK_START unsigned long long ck_ = clock64()
+#define AFE_CK(k) do { const unsigned long long c_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_afe_ck[k] += c_ - ck_; ck_ = c_; } while (0)
+#else
+#define AFE_CK_START
+#define AFE_CK(k)
+#endif
+
 __global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
 {
     __shared__ CcTileLds<false> L;
@@ -736,6 +754,7 @@ __global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
         long long left = nceps - j0;
         const int nv = (int)(left < 0 ? 0 : (left > nrow ? nrow : left));
         float *dst = a.feat_cc + (c0 + j0) * SEA_CC_NCEP;
+        AFE_CK_START;
         if (nv > 0) {
             /* frameBuf of ParmInterface.c:281 for cepstral frame j: Data[-1..199] = the float NoiseSup stream from
              * sample 80 (f0 + j) - 1 on; Data[-1] of the utterance's first cepstral frame is 0 */
@@ -762,6 +781,7 @@ __global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
                 }
             }
             wave_sync();
+            AFE_CK(0);
             float energy = 0.0f; /* WaveProc.c:423-427, lane = frame */
             if (lane < nv) {
                 const float *p = L.span + 201 * lane;
@@ -772,15 +792,19 @@ __global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
                 }
             }
             const unsigned long long pass = __ballot(lane < nv && (double)energy >= 100.0);
+            AFE_CK(1);
 #if SEA_WP_ROWS
             for (int g = 0; g < nv; g += 4) { /* four frames at a time: their peak searches run side by side */
                 const unsigned m4 = (unsigned)(pass >> g) & 0xfu;
                 if (m4 == 0) continue;
                 for (int r = 0; r < 4; ++r)
                     if ((m4 >> r) & 1u) wp_smooth(W, r, L.span + 201 * (g + r) + 1, lane);
+                AFE_CK(2);
                 wp_peaks4(W, m4, lane);
+                AFE_CK(3);
                 for (int r = 0; r < 4; ++r)
                     if ((m4 >> r) & 1u) wp_window(W, r, L.span + 201 * (g + r) + 1, lane);
+                AFE_CK(4);
             }
 #else
             for (int f = 0; f < nv; ++f)
@@ -792,6 +816,10 @@ __global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
 #endif
             wave_sync();
             cc_tile<false>(L, C, nv, dst, lane);
+            AFE_CK(5);
+#ifdef SEA_AFE_TIMING
+            if (blockIdx.x == 0 && threadIdx.x == 0) g_afe_ck[7] += 1;
+#endif
         }
         for (int idx = nv * SEA_CC_NCEP + lane; idx < nrow * SEA_CC_NCEP; idx += kLanes) dst[idx] = 0.0f;
     }

@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""tools/afe_phases.py -- (GPU box, SEA_MI355X_LIB=ablate/libsea_<v>.so built with
+``tools/build_variant.sh <v> speech_enhancement_amd/csrc/cc_kernel.hip -DSEA_AFE_TIMING``) shader clocks per 16-frame tile
+workgroup 0 of afe_ceps_kernel spends in each step (two waves share a SIMD: wall-clock shares, not lone costs)."""
 import ctypes, os, sys, json, subprocess
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
