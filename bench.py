@@ -497,11 +497,21 @@ def also_lines(batch, ids, device, steps):
                                           w16.data_ptr(), st16.data_ptr(), B, nf, 1, st) == 0
     ker, wall = timed_steps(run16, max(2, steps // 2), 1)
     assert int(pr16.sum().item()) == B * (nf - 4)
+    # the same samples as twice the streams of half the length: two wavefronts per SIMD instead of one
+    B2, nf2 = 2 * B, nf // 2
+
+    def run16b():
+        assert lib.sea_ns16k_streams_push(fr.data_ptr(), o16.data_ptr(), pr16.data_ptr(), fl16.data_ptr(), ct16.data_ptr(),
+                                          w16.data_ptr(), st16b.data_ptr(), B2, nf2, 1, st) == 0
+    st16b = torch.zeros((B2, lib.sea_ns16k_state_floats()), dtype=torch.float32, device=device)
+    ker2, wall2 = timed_steps(run16b, max(2, steps // 2), 1)
     line("NoiseSup, 16 k-native variant", f"SURVEY 8(f) #4: {B} streams x {nf} frames of 160 samples through the variant behind "
          "etsi_denoise_mapping_* (window 480, rfft (x, 512, 8), 25 gammatone-shaped windows), one wavefront per stream",
          B * nf, "frames/s", B * nf * (2 * 640 + 100 + 9), ker, wall, "sea::ns16k_stream_kernel", "ns16k_bytes_per_launch",
-         {"rtf": wall / (B * nf * 160 / 16000.0)})
-    del fr, o16, w16
+         {"rtf": wall / (B * nf * 160 / 16000.0),
+          "as_twice_the_streams_of_half_the_length": {"streams": B2, "frames": nf2, "value": B2 * nf2 / wall2, "unit": "frames/s",
+                                                      "ms_per_step": wall2 * 1e3, "avg_launch_ms": ker2 * 1e3}})
+    del fr, o16, w16, st16b
 
     # rfft256 on a streaming batch: 2^21 frames = 2 GiB in + 2 GiB out, 16 x the 256 MiB Infinity Cache (the HBM
     # figure), and 2^18 frames = 256 MiB + 256 MiB, which partly lives in that cache (kept for comparison with round 2)

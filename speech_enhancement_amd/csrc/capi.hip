@@ -693,7 +693,9 @@ int sea_ns16k_streams_push(const float *d_in, float *d_out, int *d_produced, uns
     a.tables = c->ns16;
     a.nframes = nframes;
     a.reset = reset;
-    hipLaunchKernelGGL(sea::ns16k_stream_kernel, dim3(n_streams), dim3(64), 0, (hipStream_t)stream, a);
+    a.n_streams = n_streams;
+    constexpr int G = sea::kNs16StreamsPerGroup;
+    hipLaunchKernelGGL(sea::ns16k_stream_kernel, dim3((n_streams + G - 1) / G), dim3(64 * G), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -51,12 +51,18 @@ struct __attribute__((aligned(16))) Ns16Lds {
     float gam[32];            /* the 25 window outputs */
     float fir[20];            /* 17 taps */
     float sq2[kHop];          /* VAD: squares of the first stage's current frame */
+};
+
+/* constants staged once per launch and shared by the kNs16Waves streams of a workgroup */
+struct __attribute__((aligned(16))) Ns16Tab {
     float ones[kSpecPad];     /* 1.0f: the "window" of the plain in-order sums that ride along with DoGamma */
     float gammaC[SEA16_NGAM][kSpecPad]; /* [c][i], rows 132 floats apart: the 25 lanes' float4 reads fall on different banks */
-    /* the analysis window and the digit-reversal places, staged once per launch */
-    float sigWindow[SEA16_NFFT];
-    unsigned short rev[SEA16_NFFT];
+    float sigWindow[SEA16_NFFT];        /* the analysis window */
+    unsigned short rev[SEA16_NFFT];     /* the digit-reversal places */
 };
+/* streams (= wavefronts) per workgroup: they only share the tables; 4 x 13 KB + 16.8 KB leaves room for two workgroups,
+ * eight streams, per CU (one stream per workgroup: 29.8 KB each, five per CU) */
+constexpr int kNs16Waves = kNs16StreamsPerGroup;
 
 /* rfft (x, 512, 8) on L.work, elements already at their digit-reversed places.  A pass = up to three butterflies per
  * lane, one per slot, the kind of each slot fixed by the pass (sea_tables.h): straight-line code -- every lane reads the
@@ -290,7 +296,7 @@ __device__ __forceinline__ void ns16_frame_sums(const float *sq, const float *sq
 
 /* one stage of one frame (:1207-1366) */
 template <int ST>
-__device__ __forceinline__ void ns16_stage(Ns16Lds &L, NsRegs &s, NsFd &fd, const Ns16Fft &fft, float eps, const float (&idct)[SEA16_NGAM],
+__device__ __forceinline__ void ns16_stage(Ns16Lds &L, const Ns16Tab &T, NsRegs &s, NsFd &fd, const Ns16Fft &fft, float eps, const float (&idct)[SEA16_NGAM],
                                            float irWin, int lane, int &fdBits, float &gainOut, float vadSum)
 {
     CK16_START;
@@ -299,8 +305,8 @@ __device__ __forceinline__ void ns16_stage(Ns16Lds &L, NsRegs &s, NsFd &fd, cons
 #pragma unroll
     for (int k = 0; k < SEA16_NFFT / kLanes; ++k) {
         const int i = lane + kLanes * k;
-        const float v = (i < SEA16_WIN) ? buf[SEA16_AWIN + i] * L.sigWindow[i] : 0.0f;
-        L.work[L.rev[i]] = v;
+        const float v = (i < SEA16_WIN) ? buf[SEA16_AWIN + i] * T.sigWindow[i] : 0.0f;
+        L.work[T.rev[i]] = v;
     }
     wave_sync();
     CK16(ST * 10 + 0);
@@ -369,7 +375,7 @@ __device__ __forceinline__ void ns16_stage(Ns16Lds &L, NsRegs &s, NsFd &fd, cons
     float sum = 0.0f;
     {
         const float *src = (lane == 27) ? L.bins[ST == 0 ? 2 : 1] : L.W;
-        const float *coef = (lane < SEA16_NGAM) ? L.gammaC[lane] : ((lane == 26) ? L.W : L.ones);
+        const float *coef = (lane < SEA16_NGAM) ? T.gammaC[lane] : ((lane == 26) ? L.W : T.ones);
 #pragma unroll 8
         for (int q = 0; q < SEA16_GLEN / 4; ++q) {
             const float4 w = *reinterpret_cast<const float4 *>(src + 4 * q);
@@ -466,27 +472,30 @@ static_assert(kBlobScal16 + 32 == kNs16StateFloats, "state blob layout");
 
 } // namespace
 
-__global__ void __launch_bounds__(64) ns16k_stream_kernel(Ns16StreamArgs a)
+__global__ void __launch_bounds__(64 * kNs16Waves, 2) ns16k_stream_kernel(Ns16StreamArgs a)
 {
-    __shared__ Ns16Lds L;
-    const int lane = threadIdx.x, b = blockIdx.x;
+    __shared__ Ns16Tab T;
+    __shared__ Ns16Lds LS[kNs16Waves];
+    const int lane = threadIdx.x & (kLanes - 1), wave = threadIdx.x >> 6, b = blockIdx.x * kNs16Waves + wave;
     const sea_ns16k_tables *t = a.tables;
+    for (int i = threadIdx.x; i < SEA16_GLEN * SEA16_NGAM; i += kLanes * kNs16Waves) T.gammaC[i % SEA16_NGAM][i / SEA16_NGAM] = (&t->gammaT[0][0])[i];
+    for (int i = threadIdx.x; i < kSpecPad; i += kLanes * kNs16Waves) T.ones[i] = 1.0f;
+    for (int i = threadIdx.x; i < SEA16_NFFT; i += kLanes * kNs16Waves) {
+        T.sigWindow[i] = t->sigWindow[i];
+        T.rev[i] = t->rev[i];
+    }
+    __syncthreads(); /* the only workgroup barrier: from here on every wavefront runs its own stream */
+    if (b >= a.n_streams) return;
+    Ns16Lds &L = LS[wave];
     NsRegs s;
     NsFd fd;
     float *blob = a.state + (size_t)b * kNs16StateFloats;
-
-    for (int i = lane; i < SEA16_GLEN * SEA16_NGAM; i += kLanes) L.gammaC[i % SEA16_NGAM][i / SEA16_NGAM] = (&t->gammaT[0][0])[i];
-    for (int i = lane; i < kSpecPad; i += kLanes) L.ones[i] = 1.0f;
     Ns16Fft fft;
 #pragma unroll
     for (int p = 0; p < SEA16_FFT_PASSES; ++p) {
 #pragma unroll
         for (int k = 0; k < SEA16_FFT_SLOTS; ++k) fft.slot[p][k] = t->fftSlot[p][k][lane];
         fft.tw[p] = *reinterpret_cast<const float4 *>(t->fftTw[p][(fft.slot[p][2] >> 16) & 0xffu]);
-    }
-    for (int i = lane; i < SEA16_NFFT; i += kLanes) {
-        L.sigWindow[i] = t->sigWindow[i];
-        L.rev[i] = t->rev[i];
     }
     const float eps = t->eps;
     float idct[SEA16_NGAM];
@@ -560,13 +569,13 @@ __global__ void __launch_bounds__(64) ns16k_stream_kernel(Ns16StreamArgs a)
             s.nIn1++;
             if (s.nIn1 - s.nIn2 > 2) { /* :1212 */
                 float unused;
-                ns16_stage<0>(L, s, fd, fft, eps, idct, irWin, lane, fdBits, unused, vadSum);
+                ns16_stage<0>(L, T, s, fd, fft, eps, idct, irWin, lane, fdBits, unused, vadSum);
                 s.nIn2++;
                 counter = s.nbFrame[0];
             }
             if (s.nIn2 - s.nOut2 > 2) { /* :1230 */
                 int unused = 0;
-                ns16_stage<1>(L, s, fd, fft, eps, idct, irWin, lane, unused, gain, 0.0f);
+                ns16_stage<1>(L, T, s, fd, fft, eps, idct, irWin, lane, unused, gain, 0.0f);
                 s.nOut2++;
                 produced = 1;
             }

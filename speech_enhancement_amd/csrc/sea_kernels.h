@@ -56,7 +56,9 @@ struct Ns16StreamArgs {
     const sea_ns16k_tables *tables;
     int nframes;
     int reset;
+    int n_streams;
 };
+constexpr int kNs16StreamsPerGroup = 4; /* wavefronts = streams per workgroup of ns16k_stream_kernel */
 
 struct CepsArgs {
     const float *den_f32;      /* float NoiseSup stream written by ns_denoise_kernel */

@@ -10,6 +10,8 @@ mkdir -p $O
 cd $R
 python bench.py > $O/${TAG}_bench_n1.json 2> $O/${TAG}_bench_n1.err || { tail -5 $O/${TAG}_bench_n1.err; exit 1; }
 python tools/bench_extra.py --what subband,afe,host --steps 5 > $O/${TAG}_bench_extra_1024.jsonl 2> /dev/null
+python tools/ns16k_time.py 1024 400 > $O/${TAG}_ns16k_time.txt 2> /dev/null
+python tools/ns16k_time.py 4096 200 >> $O/${TAG}_ns16k_time.txt 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_tr
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_tr -- python3 $R/bench.py --steps 10 --no-cpu-baseline --no-end-to-end > /tmp/p_tr.log 2>&1
