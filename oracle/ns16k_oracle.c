@@ -36,92 +36,11 @@
 #include "sea_oracle.h"
 
 #define PI2_D 6.28318530717958647692
-#define PI_D 3.14159265358979323846
-#define SQRT2_D 1.41421356237309504880
 
 enum { HOP = 160, WIN = 480, NFFT = 512, NSPEC = 129, NGAM = 25, GLEN = 128, NBUF = 640, DATAIN = 480, AWIN = 80, NTAP = 17, HALF = 8 };
 
-/* ---- rfft.cpp:46-181 as the variant calls it: n = 512, m = 8 (levels n2 = 4 .. 256) ---------------------------- */
-void ora16_rfft(float *x, int n, int m)
-{
-    int i, j, k, is, id, n2, n4, n8;
-    /* digit reverse counter (:57-79) */
-    j = 0;
-    for (i = 0; i < n - 1; i++) {
-        if (i < j) {
-            float t = x[j];
-            x[j] = x[i];
-            x[i] = t;
-        }
-        k = n >> 1;
-        while (k <= j) {
-            j -= k;
-            k >>= 1;
-        }
-        j += k;
-    }
-    for (is = 0, id = 4; is < n - 1; is = 2 * id - 2, id *= 4) /* :82-96 */
-        for (i = is; i < n; i += id) {
-            float a0 = x[i];
-            x[i] = a0 + x[i + 1];
-            x[i + 1] = a0 - x[i + 1];
-        }
-    for (k = 1, n2 = 2; k < m; k++) { /* :99-179 */
-        float e;
-        n2 <<= 1;
-        n4 = n2 >> 2;
-        n8 = n2 >> 3;
-        e = (float)((PI_D * 2) / n2);
-        for (is = 0, id = n2 << 1; is < n; is = 2 * id - n2, id *= 4)
-            for (i = is; i <= n - 1; i += id) {
-                int i1 = i, i2 = i1 + n4, i3 = i2 + n4, i4 = i3 + n4;
-                float t1 = x[i4] + x[i3], t2;
-                x[i4] -= x[i3];
-                x[i3] = x[i1] - t1;
-                x[i1] += t1;
-                if (n4 != 1) {
-                    i1 += n8;
-                    i2 += n8;
-                    i3 += n8;
-                    i4 += n8;
-                    t1 = (float)((double)(x[i3] + x[i4]) / SQRT2_D);
-                    t2 = (float)((double)(x[i3] - x[i4]) / SQRT2_D);
-                    x[i4] = x[i2] - t1;
-                    x[i3] = -x[i2] - t1;
-                    x[i2] = x[i1] - t2;
-                    x[i1] = x[i1] + t2;
-                }
-            }
-        for (j = 1; j < n8; j++) {
-            float a = j * e, a3 = 3 * a;
-            float cc1 = cosf(a), ss1 = sinf(a), cc3 = cosf(a3), ss3 = sinf(a3); /* C++: the float overloads */
-            for (is = 0, id = n2 << 1; is < n; is = 2 * id - n2, id *= 4)
-                for (i = is; i <= n - 1; i += id) {
-                    int i1 = i + j, i2 = i1 + n4, i3 = i2 + n4, i4 = i3 + n4;
-                    int i5 = i + n4 - j, i6 = i5 + n4, i7 = i6 + n4, i8 = i7 + n4;
-                    float t1 = x[i3] * cc1 + x[i7] * ss1;
-                    float t2 = x[i7] * cc1 - x[i3] * ss1;
-                    float t3 = x[i4] * cc3 + x[i8] * ss3;
-                    float t4 = x[i8] * cc3 - x[i4] * ss3;
-                    float t5 = t1 + t3, t6 = t2 + t4;
-                    t3 = t1 - t3;
-                    t4 = t2 - t4;
-                    t2 = x[i6] + t6;
-                    x[i3] = t6 - x[i6];
-                    x[i8] = t2;
-                    t2 = x[i2] - t3;
-                    x[i7] = -x[i2] - t3;
-                    x[i4] = t2;
-                    t1 = x[i1] + t5;
-                    x[i6] = x[i1] - t5;
-                    x[i1] = t1;
-                    t1 = x[i5] + t4;
-                    x[i5] = x[i5] - t4;
-                    x[i2] = t1;
-                }
-        }
-    }
-}
+/* The transform: ora16_rfft (ns_oracle.c) = the butterfly schedule of the etsi/ restatement with the twiddles of the C++
+ * build; the variant calls it with (512, 8) -- the index patterns of a 512-point transform, eight of its nine levels. */
 
 /* ---- tables -------------------------------------------------------------------------------------------------- */
 typedef struct {

@@ -73,14 +73,18 @@ static void bf_twiddle(float *x, int i, int j, int n4, float cc1, float ss1, flo
     x[i2] = t1;
 }
 
-void ora_rfft(float *x, int n, int m)
+/* n: the length the digit-reverse counter and the index patterns run on; m: the number of levels (the reference's
+ * callers pass m = log2 n, except the 16 k-native variant: (512, 8)); cxx: the twiddles as the C++ build of the same
+ * text computes them (cos / sin of a float are the float overloads there: aurora_etsi/rfft.cpp) */
+static void rfft_core(float *x, int n, int m, int cxx)
 {
-    int i, j, k, is, id, n2, n4, n8;
+    int i, j, k, is, id, n2, n4, n8, bits = 0;
 
-    /* bit reversal (rfft.c:57-79 implements the classic in-place bit-reversed swap) */
+    /* bit reversal (rfft.c:57-79 implements the classic in-place bit-reversed swap over log2 n bits) */
+    while ((1 << bits) < n) bits++;
     for (i = 0; i < n; i++) {
         int r = 0;
-        for (k = 0; k < m; k++) r |= ((i >> k) & 1) << (m - 1 - k);
+        for (k = 0; k < bits; k++) r |= ((i >> k) & 1) << (bits - 1 - k);
         if (i < r) { float t = x[i]; x[i] = x[r]; x[r] = t; }
     }
     /* length-two butterflies on the split-radix index pattern (rfft.c:82-96) */
@@ -104,13 +108,16 @@ void ora_rfft(float *x, int n, int m)
             }
         for (j = 1; j < n8; j++) {
             float a = j * e, a3 = 3 * a;
-            float cc1 = (float)cos((double)a), ss1 = (float)sin((double)a);
-            float cc3 = (float)cos((double)a3), ss3 = (float)sin((double)a3);
+            float cc1 = cxx ? cosf(a) : (float)cos((double)a), ss1 = cxx ? sinf(a) : (float)sin((double)a);
+            float cc3 = cxx ? cosf(a3) : (float)cos((double)a3), ss3 = cxx ? sinf(a3) : (float)sin((double)a3);
             for (is = 0, id = n2 << 1; is < n; is = 2 * id - n2, id *= 4)
                 for (i = is; i < n; i += id) bf_twiddle(x, i, j, n4, cc1, ss1, cc3, ss3);
         }
     }
 }
+
+void ora_rfft(float *x, int n, int m) { rfft_core(x, n, m, 0); }   /* etsi/cpp/rfft.c, compiled as C */
+void ora16_rfft(float *x, int n, int m) { rfft_core(x, n, m, 1); } /* aurora_etsi/rfft.cpp, compiled as C++ */
 
 /* ------------------------------------------------------------------------------------------
  * Constant tables
