@@ -105,6 +105,26 @@ def main():
         else:
             bad += int(not torch.equal(irm.view(torch.int32), iref.view(torch.int32)))
     res["irm_differing"] = bad
+    # the 16 k-native NoiseSup variant: 2048 streams (two waves per SIMD) and 1024 (one), chunked differently each time
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(16)
+    fr = torch.randint(-6000, 6000, (2048, 120, 160), device=dev, generator=gen).float()
+    fr[::7, 40:44] = 0.0                      # gated frames in every seventh stream
+    nref = None
+    bad = 0
+    for k in range(max(it // 10, 3)):
+        cut = (120, 60, 1, 37)[k % 4]
+        r = sea.ns16k_streams_push(fr[:, :cut].contiguous())
+        parts = [r]
+        if cut < 120:
+            parts.append(sea.ns16k_streams_push(fr[:, cut:].contiguous(), state=r["state"]))
+        cat = [torch.cat([p[key] for p in parts], dim=1) for key in ("out", "produced", "flags", "counter", "wiener")]
+        if nref is None:
+            nref = [c.clone() for c in cat]
+        else:
+            bad += int(not all(torch.equal(a.view(torch.uint8) if a.dtype == torch.uint8 else a.view(torch.int32), b.view(torch.uint8) if b.dtype == torch.uint8 else b.view(torch.int32))
+                               for a, b in zip(cat, nref)))
+    res["ns16k_differing"] = bad
     res["seconds"] = round(time.time() - t0, 1)
     print(json.dumps(res), flush=True)
     sys.exit(1 if any(v for k, v in res.items() if k.endswith("differing")) else 0)
