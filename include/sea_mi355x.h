@@ -96,6 +96,20 @@ int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const
  * sea_ns_kernel_form(f) forces form f for later calls (0 = by batch size again; the SEA_NS_KERNEL
  * environment variable = single | pipe | pipe6 | big sets the initial value); returns the previous one. */
 int sea_ns_kernel_form(int form);
+/* The same for one TIME SLICE of every utterance: a batch may be cut along the time axis and run as one launch per
+ * slice, so that a caller can upload slice k + 1 and download slice k - 1 while slice k is on the device
+ * (sea_denoise_utterances does).  d_in / d_out / d_offsets / d_lengths describe THIS slice (each utterance's frames of
+ * the slice, packed like a batch of their own); d_state holds sea_ns_slice_state_floats() floats per utterance --
+ * utterance u of every slice is the same utterance -- and carries the recursion (DoNoiseSup's state, the pipeline's
+ * sample rings, the DC filter, the zero-frame gate) from launch to launch; resume = 0 for the first slice.  The slices
+ * of an utterance must be whole frames except the last; frame_base = the utterance's frames before this slice
+ * (d_first_out, optional, is the absolute frame index of the first NoiseSup output).  Results are those of the one
+ * launch: tests/test_gpu_parity.py::test_ns_time_slices_equal_one_launch. */
+int sea_ns_denoise_batch_slice(const short *d_in, short *d_out, float *d_out_f32, const long long *d_offsets,
+                               const long long *d_lengths, const int *d_order, int *d_first_out, float *d_state, int n_utt,
+                               int frame_base, int resume, void *stream);
+int sea_ns_slice_state_floats(void);
+
 /* SURVEY 8(f) #3 -- the feature chain the reference keeps commented out (etsi/cpp/ParmInterface.c:274-311):
  * WaveProc -> CompCeps -> PostProc -> VAD, then FlushAdvProcess (:348-354).
  * Step 1: NoiseSup that also stores what the frame-dropping VAD votes over.  d_flags: one byte per

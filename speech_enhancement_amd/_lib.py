@@ -52,6 +52,8 @@ PROTOTYPES = {
     "sea_ns_stream_push": (_i, [_vp, _vp, _vp]),
     "sea_ns_stream_delete": (None, [_vp]),
     "sea_ns_streams_push": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sea_ns_denoise_batch_slice": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sea_ns_slice_state_floats": (_i, []),
     "sea_ns_streams_push_fd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sea_ns_state_floats": (_i, []),
     "sea_ns16k_streams_push": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

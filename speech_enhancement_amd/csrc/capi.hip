@@ -119,6 +119,14 @@ int ns_pick_form(int n_inflight, int n_cu)
 int ns_launch(const sea::NsBatchArgs &a, int form, hipStream_t stream)
 {
     if (a.n_utt <= 0) return 0;
+    if (a.state) { /* time slices: the four-wave forms only */
+        if (form == 4)
+            hipLaunchKernelGGL(sea::ns_denoise_pipe_big_slice_kernel, dim3(a.n_utt), dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL(sea::ns_denoise_pipe_slice_kernel, dim3(a.n_utt), dim3(256), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (form == 1)
         hipLaunchKernelGGL(sea::ns_denoise_kernel, dim3(a.n_utt), dim3(64), 0, stream, a);
     else if (form == 3)
@@ -215,6 +223,35 @@ int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
     if (form == 2) a.prio_row = (d_order && n_utt > c->n_cu) ? c->n_cu : 0; /* rows of the longest-first launch order */
     return ns_launch(a, form, (hipStream_t)stream);
 }
+
+/* One TIME SLICE of a batch: see include/sea_mi355x.h */
+int sea_ns_denoise_batch_slice(const short *d_in, short *d_out, float *d_out_f32, const long long *d_offsets,
+                               const long long *d_lengths, const int *d_order, int *d_first_out, float *d_state, int n_utt,
+                               int frame_base, int resume, void *stream)
+{
+    if (n_utt <= 0) return 0;
+    if (!d_state) return fail("sea_ns_denoise_batch_slice: d_state is required");
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    sea::NsBatchArgs a = {};
+    a.in = d_in;
+    a.out = d_out;
+    a.out_f32 = d_out_f32;
+    a.offsets = d_offsets;
+    a.lengths = d_lengths;
+    a.order = d_order;
+    a.first_out = d_first_out;
+    a.tables = c->ns;
+    a.n_utt = n_utt;
+    a.state = d_state;
+    a.resume = resume;
+    a.frame_base = frame_base;
+    const int form = (n_utt <= 4 * c->n_cu) ? 2 : 4;
+    if (form == 2) a.prio_row = (d_order && n_utt > c->n_cu) ? c->n_cu : 0;
+    return ns_launch(a, form, (hipStream_t)stream);
+}
+
+int sea_ns_slice_state_floats(void) { return sea::kNsPipeStateFloats; }
 
 /* ------------------------------------------------------------------------------------------- */
 int sea_ns_denoise_batch_fd(const short *d_in, short *d_out, float *d_out_f32,

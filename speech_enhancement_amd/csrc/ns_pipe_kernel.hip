@@ -210,7 +210,7 @@ __device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables 
     C.eps = t->eps;
 }
 
-template <bool FD, bool ADDR_LDS>
+template <bool FD, bool ADDR_LDS, bool SLICES = false>
 __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_LDS> &L)
 {
     const int lane = threadIdx.x & 63;
@@ -229,12 +229,23 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
     const long long nfr = a.lengths[u] / SEA_HOP;
     const long long niter = nfr + kLagS + (SEA_STORE_IN_F ? 1 : 0);
 
-    for (int i = threadIdx.x; i < 2 * (kCirc + kMirror); i += 64 * kPipeWaves) (&L.circ[0][0])[i] = 0.0f;
+    /* time slices (NsBatchArgs::state): the recursion of utterance u between two launches */
+    float *const blob = (SLICES && !FD && a.state) ? a.state + (size_t)u * kNsPipeStateFloats : nullptr;
+    const bool resume = blob && a.resume;
+    constexpr int kBlobLane = 2 * kCirc, kBlobRing = kBlobLane + 12 * 64, kBlobScal = kBlobRing + 3 * kSlots;
+    if (resume) { /* the two stage buffers with their mirrors, the tick-indexed rings */
+        for (int i = threadIdx.x; i < 2 * (kCirc + kMirror); i += 64 * kPipeWaves) {
+            const int st = i / (kCirc + kMirror), x = i - st * (kCirc + kMirror);
+            L.circ[st][x] = blob[st * kCirc + (x < kCirc ? x : x - kCirc)];
+        }
+    } else {
+        for (int i = threadIdx.x; i < 2 * (kCirc + kMirror); i += 64 * kPipeWaves) (&L.circ[0][0])[i] = 0.0f;
+    }
     for (int i = threadIdx.x; i < SEA_NMEL * 16; i += 64 * kPipeWaves) L.idctT[i] = a.tables->idct[i >> 4][i & 15];
     if (threadIdx.x < 4) L.szero[threadIdx.x] = 0.0f;
     if (threadIdx.x < kSlots) {
-        L.frameEn[threadIdx.x] = 0.0f;
-        L.denSum[threadIdx.x] = 0.0f;
+        L.frameEn[threadIdx.x] = resume ? blob[kBlobRing + threadIdx.x] : 0.0f;
+        L.denSum[threadIdx.x] = resume ? blob[kBlobRing + kSlots + threadIdx.x] : 0.0f;
     }
     if (threadIdx.x < 2) {
         L.r01[threadIdx.x].valid = 0;
@@ -261,7 +272,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
         const float irWin = a.tables->irWin[lane];
         const uint32_t *in32 = reinterpret_cast<const uint32_t *>(a.in + off);
         uint32_t nextw = (lane < 40 && nfr > 0) ? in32[lane] : 0u;
-        int tick = 0; /* frames seen since (and including) the first non-zero one */
+        int tick = resume ? __float_as_int(blob[kBlobScal + 0]) : 0; /* frames seen since (and including) the first non-zero one */
         int onset = (int)nfr;
         /* The intake of a frame (zero-frame gate, int16 -> float, store into its slot of the stage-0 buffer)
          * runs at the BOTTOM of the previous iteration, when its words (requested one iteration earlier still)
@@ -359,6 +370,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
             NS_T_END;
         }
         if (FD && a.onset_out && lane == 0) a.onset_out[u] = onset;
+        if (blob && lane == 0) blob[kBlobScal + 0] = __int_as_float(tick);
         NS_T_FLUSH(0);
 #ifdef SEA_NS_TIMING
         if (blockIdx.x < 4096 && lane == 0) {
@@ -383,6 +395,13 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
         regs_init(s, C.eps);
         NsFd fd;
         fd_init(fd);
+        if (resume) {
+            const float *p = blob + kBlobLane + lane, *q = blob + kBlobScal;
+            s.noiseLo[0] = p[0 * 64]; s.noiseHi[0] = p[1 * 64]; s.denLo[0] = p[2 * 64];
+            s.denHi[0] = p[3 * 64]; s.prevLo[0] = p[4 * 64]; s.prevHi[0] = p[5 * 64];
+            s.nbFrame[0] = __float_as_int(q[1]); s.meanEn = q[2]; s.flagVAD = __float_as_int(q[3]);
+            s.hangOver = __float_as_int(q[4]); s.nbSpeech = __float_as_int(q[5]); s.psdOk[0] = __float_as_int(q[6]);
+        }
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
             const long long f = i - 1;
@@ -412,6 +431,15 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
             block_sync();
             NS_T_END;
         }
+        if (blob) {
+            float *p = blob + kBlobLane + lane, *q = blob + kBlobScal;
+            p[0 * 64] = s.noiseLo[0]; p[1 * 64] = s.noiseHi[0]; p[2 * 64] = s.denLo[0];
+            p[3 * 64] = s.denHi[0]; p[4 * 64] = s.prevLo[0]; p[5 * 64] = s.prevHi[0];
+            if (lane == 0) {
+                q[1] = __int_as_float(s.nbFrame[0]); q[2] = s.meanEn; q[3] = __int_as_float(s.flagVAD);
+                q[4] = __int_as_float(s.hangOver); q[5] = __int_as_float(s.nbSpeech); q[6] = __int_as_float(s.psdOk[0]);
+            }
+        }
         NS_T_FLUSH(2);
     } else if (role == 2) {
         /* ---- B1: BACK of stage 1 ---- */
@@ -419,6 +447,12 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
         load_back_const(C, a.tables, lane);
         NsRegs s;
         regs_init(s, C.eps);
+        if (resume) {
+            const float *p = blob + kBlobLane + lane, *q = blob + kBlobScal;
+            s.noiseLo[1] = p[6 * 64]; s.noiseHi[1] = p[7 * 64]; s.denLo[1] = p[8 * 64];
+            s.denHi[1] = p[9 * 64]; s.prevLo[1] = p[10 * 64]; s.prevHi[1] = p[11 * 64];
+            s.nbFrame[1] = __float_as_int(q[7]); s.lowSNRtrack = q[8]; s.alfaGF = q[9]; s.psdOk[1] = __float_as_int(q[10]);
+        }
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
             const long long f = i - 3;
@@ -446,13 +480,21 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
             block_sync();
             NS_T_END;
         }
+        if (blob) {
+            float *p = blob + kBlobLane + lane, *q = blob + kBlobScal;
+            p[6 * 64] = s.noiseLo[1]; p[7 * 64] = s.noiseHi[1]; p[8 * 64] = s.denLo[1];
+            p[9 * 64] = s.denHi[1]; p[10 * 64] = s.prevLo[1]; p[11 * 64] = s.prevHi[1];
+            if (lane == 0) {
+                q[7] = __int_as_float(s.nbFrame[1]); q[8] = s.lowSNRtrack; q[9] = s.alfaGF; q[10] = __int_as_float(s.psdOk[1]);
+            }
+        }
         NS_T_FLUSH(4);
     } else {
         /* ---- S: scalar chains ---- */
         uint32_t *out32 = reinterpret_cast<uint32_t *>(a.out + off);
         float *outf = a.out_f32 ? a.out_f32 + off : nullptr;
-        float dcX = 0.0f, dcY = 0.0f; /* prevSamples, NoiseSup.c:908-909 */
-        int firstOut = -1;
+        float dcX = resume ? blob[kBlobScal + 11] : 0.0f, dcY = resume ? blob[kBlobScal + 12] : 0.0f; /* prevSamples, NoiseSup.c:908-909 */
+        int firstOut = resume ? __float_as_int(blob[kBlobScal + 13]) : -1;
         const float irWinS = (SEA_IDCT_TAIL_S > 0) ? a.tables->irWin[lane] : 0.0f;
         NS_T_CK_DECL;
         for (long long i = 0; i < niter; ++i) {
@@ -531,7 +573,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                      * was measured slower: five checks in a row per lane against two per lane here) */
                     dc_verify(L.sdif, soutS, dcY, y, lane);
                     dcY = y;
-                    if (firstOut < 0) firstOut = (int)fo;
+                    if (firstOut < 0) firstOut = (int)fo + (blob ? a.frame_base : 0);
                 }
                 NS_T_CK(3);
             }
@@ -561,8 +603,20 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
             NS_T_END;
         }
         if (a.first_out && lane == 0) a.first_out[u] = firstOut;
+        if (blob && lane == 0) {
+            blob[kBlobScal + 11] = dcX;
+            blob[kBlobScal + 12] = dcY;
+            blob[kBlobScal + 13] = __int_as_float(firstOut);
+        }
         NS_T_FLUSH(6);
         NS_T_CK_FLUSH;
+    }
+    if (blob) { /* every wave has passed the last frame barrier: nothing writes LDS any more */
+        for (int i = threadIdx.x; i < 2 * kCirc; i += 64 * kPipeWaves) blob[i] = L.circ[i / kCirc][i % kCirc];
+        if (threadIdx.x < kSlots) {
+            blob[kBlobRing + threadIdx.x] = L.frameEn[threadIdx.x];
+            blob[kBlobRing + kSlots + threadIdx.x] = L.denSum[threadIdx.x];
+        }
     }
 }
 
@@ -585,6 +639,19 @@ __global__ __launch_bounds__(256, SEA_NS_BIG_WAVES) void ns_denoise_pipe_big_ker
 {
     __shared__ p4::PipeLds<true> L;
     p4::ns_pipe_body<false, true>(a, L);
+}
+
+/* both forms for utterances processed in time slices (NsBatchArgs::state): the recursion is loaded at the start and
+ * stored at the end of the launch; kernels of their own so that the whole-utterance forms keep their register budgets */
+__global__ __launch_bounds__(256, SEA_NS_MIN_WAVES) void ns_denoise_pipe_slice_kernel(NsBatchArgs a)
+{
+    __shared__ p4::PipeLds<false> L;
+    p4::ns_pipe_body<false, false, true>(a, L);
+}
+__global__ __launch_bounds__(256, SEA_NS_BIG_WAVES) void ns_denoise_pipe_big_slice_kernel(NsBatchArgs a)
+{
+    __shared__ p4::PipeLds<true> L;
+    p4::ns_pipe_body<false, true, true>(a, L);
 }
 
 /* the same pipeline with the first stage's speech measures (SpeechQVar/Spec/Mel, VADNS) evaluated in

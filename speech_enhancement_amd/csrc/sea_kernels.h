@@ -27,7 +27,17 @@ struct NsBatchArgs {
     int *onset_out;            /* per utterance: index of the first non-zero frame (number of frames if none) */
     int prio_row;              /* > 0: workgroups [k * prio_row, (k+1) * prio_row) get issue priority 3 - k - prio_base (four-wave form only) */
     int prio_base;             /* rows to skip: a later chunk of a batch launched in pieces (hostpipe.hip) starts below the first */
+    /* An utterance processed in TIME SLICES, one launch per slice (four-wave forms without speech flags only): state != nullptr
+     * makes every workgroup store its recursion at the end of the launch -- kNsPipeStateFloats floats at state + u * that --
+     * and, with resume != 0, start from what the previous slice stored instead of DoNoiseSupInit's state.  in / out /
+     * offsets / lengths describe the slice; frame_base = frames of the utterance before this slice (first_out is absolute). */
+    float *state;
+    int resume;
+    int frame_base;
 };
+/* [2 x 640 stage buffers as 8-slot rings][12 x 64 per-lane spectra: noise, den, previous PSD of (lane, 64) x 2 stages]
+ * [8 frame energies][8 denSigSE1 sums][8 speech-flag words][40 scalars] */
+constexpr int kNsPipeStateFloats = 2 * 640 + 12 * 64 + 3 * 8 + 40;
 
 /* B independent streams, nframes frames of 80 floats each, state blobs of kNsStateFloats floats */
 constexpr int kNsStateFloats = 2 * 320 + 12 * 64 + 32;
@@ -135,6 +145,8 @@ __global__ void ns_denoise_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_big_kernel(NsBatchArgs a); /* lower-register form for > 4 utterances per CU */
 __global__ void ns_denoise_pipe_fd_kernel(NsBatchArgs a);
+__global__ void ns_denoise_pipe_slice_kernel(NsBatchArgs a);     /* time slices: state in / out (NsBatchArgs::state) */
+__global__ void ns_denoise_pipe_big_slice_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe6_kernel(NsBatchArgs a);    /* six waves per utterance (ns_pipe6_kernel.hip) */
 __global__ void ns_denoise_pipe6_fd_kernel(NsBatchArgs a); /* + speech flags for the frame-dropping VAD */
 __global__ void ns_stream_kernel(NsStreamArgs a);

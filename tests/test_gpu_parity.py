@@ -891,3 +891,61 @@ def test_ns_all_kernel_forms_agree(oracle):
                         f"form {form}, utterance {u}: float stream"
     finally:
         lib.sea_ns_kernel_form(prev)
+
+
+def test_ns_time_slices_equal_one_launch(oracle):
+    """sea_ns_denoise_batch_slice: the batch cut along the TIME axis, one launch per slice with the recursion carried in
+    a state blob per utterance (what sea_denoise_utterances pipelines against its PCIe copies).  Cut points that fall
+    inside leading-zero runs, inside the pipeline's four frames of latency, slices of a single frame, utterances that
+    end before later slices start: int16 output, float stream and the index of the first output frame equal the oracle's
+    (= the one-launch result) bit for bit, for both kernel forms the slices use."""
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    torch = _torch()
+    lib = sea.load()
+    utts = _mixed_corpus()
+    utts += [corpus.synth_utterance(50 + n, 80 * n + (n * 13) % 80) for n in range(13)]
+    utts += [np.concatenate([np.zeros(80 * k, np.int16), corpus.synth_utterance(70 + k, 80 * (7 + k % 2))]) for k in (1, 2, 3, 4, 5)]
+    utts += [corpus.synth_utterance(90, 80 * 41), corpus.synth_utterance(91, 80 * 40 + 5)]
+    utts.sort(key=len, reverse=True)                       # slices keep a PREFIX of the list: longest first
+    traces = [oracle.ns_trace(x, want_state=False) for x in utts]
+    nfr = np.array([len(x) // 80 for x in utts])
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    for bounds, rep in (((0, 1, 2, 3, 5, 9, 10, 40, 41, 97, int(nfr.max())), 1),       # the four-wave form
+                        ((0, 7, 64, int(nfr.max())), 4 * n_cu // len(utts) + 1)):      # > 4 utterances per CU: the lower-register form
+        pairs = sorted(list(zip(utts, traces)) * rep, key=lambda p: len(p[0]), reverse=True)
+        ulist, tlist = [p[0] for p in pairs], [p[1] for p in pairs]
+        n = len(ulist)
+        nf = np.array([len(x) // 80 for x in ulist])
+        state = torch.zeros((n, lib.sea_ns_slice_state_floats()), dtype=torch.float32, device="cuda")
+        first = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        outs, outf = [[] for _ in range(n)], [[] for _ in range(n)]
+        for k in range(len(bounds) - 1):
+            b0, b1 = bounds[k], bounds[k + 1]
+            act = int(np.sum(nf > b0))                      # a prefix, by the sort
+            if act == 0:
+                break
+            parts = []
+            for u in range(act):
+                last = b1 >= nf[u]
+                parts.append(ulist[u][80 * b0: (len(ulist[u]) if last else 80 * b1)])   # the trailing partial frame rides with the last slice
+            sl = sea.PackedBatch.from_arrays(parts)
+            o = torch.full_like(sl.data, -5)
+            f32 = torch.zeros(sl.total, dtype=torch.float32, device="cuda")
+            rc = lib.sea_ns_denoise_batch_slice(sl.data.data_ptr(), o.data_ptr(), f32.data_ptr(), sl.offsets.data_ptr(), sl.lengths.data_ptr(),
+                                                None, first.data_ptr(), state.data_ptr(), act, b0, int(k > 0), None)
+            assert rc == 0, lib.sea_last_error()
+            torch.cuda.synchronize()
+            for u, (a, b) in enumerate(zip(sl.split(o, full_frames_only=True), sl.split(f32, full_frames_only=True))):
+                outs[u].append(a)
+                outf[u].append(b)
+        first_h = first.cpu().numpy()
+        for u in range(n):
+            tr, x = tlist[u], ulist[u]
+            got = np.concatenate(outs[u]) if outs[u] else np.zeros(0, np.int16)
+            assert np.array_equal(got, tr["out_i16"][: nf[u] * 80]), f"{len(bounds) - 1} slices, utterance {u} (L={len(x)})"
+            if nf[u]:
+                assert int(first_h[u]) == (nf[u] - tr["nout"] if tr["nout"] else -1), f"utterance {u}: first output"
+            if tr["nout"]:
+                f0 = nf[u] - tr["nout"]
+                assert np.array_equal(np.concatenate(outf[u])[f0 * 80: nf[u] * 80].view(np.uint32), tr["den_f32"].view(np.uint32)), f"utterance {u}: float stream"
