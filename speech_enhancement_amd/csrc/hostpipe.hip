@@ -7,14 +7,18 @@
  *   sea_resynth_utterances   the same for resynth() (resyth_64sub_ori/cpp/main.cpp:84-145)
  *
  * PCIe is the slow link of these entry points (160 B per NoiseSup frame each way against 320 B of HBM traffic
- * on the device), so the list is cut into chunks that travel down a pipeline:
+ * on the device), so the list is cut into pieces that travel down a pipeline:
  *
- *   pool threads   pack chunk k+1 into pinned staging            | unpack chunk k-1 into the caller's buffers
- *   stream k % S   H2D chunk k -> kernel over chunk k -> D2H chunk k
+ *   pool threads   pack piece k+1 into pinned staging            | unpack piece k-1 into the caller's buffers
+ *   copy engines   H2D piece k+1                                 | D2H piece k-1
+ *   device         kernel over piece k
  *
- * Utterances are sorted longest first (the kernels' run time is their longest utterance's chain of frames), the
- * chunks are contiguous ranges of that order, every chunk is one launch on its own slice of ONE device buffer.
- * Results do not depend on the cut: an utterance is processed by one workgroup whatever its neighbours.
+ * NoiseSup (sea_denoise_utterances): the pieces are TIME SLICES of the whole list -- frames [B_k, B_k+1) of every
+ * utterance, one launch per slice, the recursion carried in a state blob per utterance (denoise_utterances_slices).
+ * A launch over whole utterances lasts as long as its longest utterance's chain of frames whatever its size; a slice lasts
+ * as long as its own frames.  Resynthesis (sea_resynth_utterances; its second pass runs backwards over the utterance) and
+ * SEA_HOST_MODE=chunks: the pieces are chunks of whole utterances, sorted longest first, one launch per chunk on its own
+ * part of ONE device buffer.  Results do not depend on either cut.
  * Staging, device buffers, streams and events are grow-only and belong to the calling host thread (the reference's
  * batch tool calls etsi_denoise from N threads); the packing threads are one process-wide pool.
  */
@@ -203,6 +207,8 @@ struct PipeWs {
     Grow<long long> meta;  /* offsets | lengths | mask offsets, in launch order */
     float *d_inter = nullptr; /* resynth scratch */
     size_t inter_bytes = 0;
+    float *d_state = nullptr; /* NoiseSup in time slices: the recursion per utterance between two launches */
+    size_t state_floats = 0;
     hipStream_t stream[kMaxStreams] = {};
     hipEvent_t ev_meta = nullptr, ev_done[kMaxChunks] = {}, ev_kernel[kMaxChunks] = {}, ev_h2d[kMaxChunks] = {};
     int device = -1;
@@ -219,6 +225,9 @@ struct PipeWs {
         if (d_inter) (void)hipFree(d_inter);
         d_inter = nullptr;
         inter_bytes = 0;
+        if (d_state) (void)hipFree(d_state);
+        d_state = nullptr;
+        state_floats = 0;
         for (auto &s : stream) {
             if (s) (void)hipStreamDestroy(s);
             s = nullptr;
@@ -268,6 +277,17 @@ struct PipeWs {
         inter_bytes = 0;
         hipError_t e = hipMalloc((void **)&d_inter, bytes + 16);
         if (e == hipSuccess) inter_bytes = bytes;
+        return e;
+    }
+    hipError_t ensure_state(size_t floats)
+    {
+        if (floats <= state_floats) return hipSuccess;
+        if (d_state) (void)hipFree(d_state);
+        d_state = nullptr;
+        state_floats = 0;
+        const size_t want = floats + floats / 4;
+        hipError_t e = hipMalloc((void **)&d_state, want * sizeof(float));
+        if (e == hipSuccess) state_floats = want;
         return e;
     }
     void drain()
@@ -330,7 +350,11 @@ extern "C" {
 int sea_host_threads(void) { return Pool::get().size(); }
 
 /* ---------------------------------------------------------------------------------------------------- */
-int sea_denoise_utterances(const short *const *in, short *const *out, const long *lengths, int n_utt)
+static int denoise_utterances_slices(const short *const *in, short *const *out, const long *lengths, int n_utt);
+
+/* SEA_HOST_MODE=chunks: the list cut into chunks of whole utterances, one launch per chunk on its own stream (round 3's
+ * first pipeline, kept for A/B).  Default: time slices (denoise_utterances_slices below). */
+static int denoise_utterances_chunks(const short *const *in, short *const *out, const long *lengths, int n_utt)
 {
     if (n_utt <= 0) return 0;
     DeviceCtx *dc;
@@ -491,6 +515,189 @@ int sea_denoise_utterances(const short *const *in, short *const *out, const long
         }
         for (auto &e : tev) (void)hipEventDestroy(e);
     }
+    scope.ok = true;
+    return 0;
+}
+
+int sea_denoise_utterances(const short *const *in, short *const *out, const long *lengths, int n_utt)
+{
+    const char *m = getenv("SEA_HOST_MODE");
+    if ((m && !strcmp(m, "chunks")) || kStreams < 3) return denoise_utterances_chunks(in, out, lengths, n_utt);
+    return denoise_utterances_slices(in, out, lengths, n_utt);
+}
+
+/* The list cut along the TIME axis: slice k holds the frames [B_k, B_k+1) of every utterance that has them, packed like a
+ * batch of its own, and is one launch over all those utterances (sea_ns_denoise_batch_slice: the recursion travels in a
+ * state blob per utterance).  A launch then lasts as long as ITS frames take -- a chunk of whole utterances lasts as long
+ * as its longest utterance, whatever its size -- so the pipeline
+ *     pool threads  pack slice k+1            | unpack slice k-1
+ *     copy engines  H2D slice k+1             | D2H slice k-1
+ *     device        kernel over slice k
+ * has short fill and drain phases: the first kernel starts after 1/K of the upload, the last download carries 1/K of the
+ * output.  Slice boundaries equalise the slices' sample counts (SEA_HOST_SLICES of them, default 8: measured on the
+ * 1024-utterance bench corpus, tools/host_slices_sweep.sh, alternating on one box -- chunks of whole utterances 7.4 ms,
+ * 4 slices 6.2-6.5, 6: 5.9-6.0, 8: 4.8-5.7, 10: 5.6-5.7, 12: 5.3-5.8, 16: 5.8 ms; what is left is the pool's memcpy
+ * rate: 2 x 131 MB packed and unpacked in that time).
+ * Three streams, one per job -- uploads, kernels (in order: slice k needs slice k - 1's state), downloads: with one
+ * stream per slice, reused round robin, a slice's download ended up queued behind a later slice's kernel (calls of
+ * 13-20 ms among the 6 ms ones). */
+static int denoise_utterances_slices(const short *const *in, short *const *out, const long *lengths, int n_utt)
+{
+    if (n_utt <= 0) return 0;
+    DeviceCtx *dc;
+    if (ctx(&dc)) return 1;
+    for (int u = 0; u < n_utt; ++u)
+        if (lengths[u] < 0) return fail("negative length for utterance %d", u);
+    std::vector<int> idx(n_utt);
+    for (int i = 0; i < n_utt; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return lengths[a] > lengths[b]; });
+    std::vector<long long> nfr(n_utt);
+    long long total_fr = 0;
+    for (int j = 0; j < n_utt; ++j) total_fr += (nfr[j] = lengths[idx[j]] / 80);
+    if (total_fr == 0) return 0;
+    const long long max_fr = nfr[0];
+    const long long total = total_fr * 80;
+
+    /* slice boundaries in frames: equal shares of the samples */
+    const bool small = total * 2 < (2 << 20) || Pool::get().size() <= 1;
+    int want = small ? 1 : (int)env_mb("SEA_HOST_SLICES", 8);
+    want = (int)std::min<long long>(std::min(want, kMaxChunks), std::max<long long>(1, max_fr / 8));
+    auto frames_below = [&](long long f) {
+        long long s = 0;
+        for (int j = 0; j < n_utt; ++j) s += std::min(nfr[j], f);
+        return s;
+    };
+    std::vector<long long> B(1, 0);
+    for (int k = 1; k < want; ++k) {
+        long long lo = B.back() + 1, hi = max_fr; /* smallest f with frames_below(f) >= share */
+        const long long share = total_fr * k / want;
+        while (lo < hi) {
+            const long long mid = (lo + hi) / 2;
+            if (frames_below(mid) >= share) hi = mid; else lo = mid + 1;
+        }
+        if (lo >= max_fr) break;
+        B.push_back(lo);
+    }
+    B.push_back(max_fr);
+    const int K = (int)B.size() - 1;
+
+    /* per slice: the active prefix of the sorted list, packed offsets (absolute, in samples) and lengths */
+    std::vector<int> nact(K);
+    std::vector<long long> soff(K + 1, 0);
+    std::vector<size_t> mbase(K + 1, 0); /* where slice k's offsets | lengths sit in the meta array */
+    for (int k = 0; k < K; ++k) {
+        int n = 0;
+        while (n < n_utt && nfr[n] > B[k]) ++n;
+        nact[k] = n;
+        long long smp = 0;
+        for (int j = 0; j < n; ++j) smp += 80 * (std::min(nfr[j], B[k + 1]) - B[k]);
+        soff[k + 1] = soff[k] + smp;
+        mbase[k + 1] = mbase[k] + 2 * (size_t)n;
+    }
+    PipeWs &w = t_ws;
+    HIP_TRY(w.bind());
+    HIP_TRY(w.in.ensure((size_t)total));
+    HIP_TRY(w.out.ensure((size_t)total));
+    HIP_TRY(w.meta.ensure(mbase[K]));
+    if (K > 1) HIP_TRY(w.ensure_state((size_t)n_utt * sea::kNsPipeStateFloats));
+    std::vector<std::vector<long long>> bpre(K); /* byte prefix per slice: task sizing */
+    for (int k = 0; k < K; ++k) {
+        long long *offs = w.meta.h + mbase[k], *lens = offs + nact[k];
+        bpre[k].assign(nact[k] + 1, 0);
+        long long o = soff[k];
+        for (int j = 0; j < nact[k]; ++j) {
+            const long long L = 80 * (std::min(nfr[j], B[k + 1]) - B[k]);
+            offs[j] = o;
+            lens[j] = L;
+            o += L;
+            bpre[k][j + 1] = bpre[k][j] + 2 * L;
+        }
+    }
+
+    std::vector<Latch> packed(K), unpacked(K);
+    Scope scope(&w);
+    short *h_in = w.in.h, *h_out = w.out.h;
+    const int *ix = idx.data();
+    for (int k = 0; k < K; ++k) {
+        const long long *offs = w.meta.h + mbase[k], *lens = offs + nact[k];
+        const long long b0 = 80 * B[k];
+        run_copies(0, nact[k], bpre[k].data(), &packed[k], &scope.all, small,
+                   [=](int j) { memcpy(h_in + offs[j], in[ix[j]] + b0, (size_t)lens[j] * sizeof(short)); });
+    }
+    hipStream_t sUp = w.stream[0], sKern = w.stream[1], sDown = w.stream[2];
+    HIP_TRY(hipMemcpyAsync(w.meta.d, w.meta.h, mbase[K] * sizeof(long long), hipMemcpyHostToDevice, sUp));
+
+    /* SEA_HOST_TRACE=n: print the timeline of this thread's calls from the n-th list of more than one slice on */
+    static std::atomic<int> n_sliced{0};
+    const char *tr = getenv("SEA_HOST_TRACE");
+    const bool trace = tr && (K == 1 ? atoi(tr) <= 0 : n_sliced++ >= atoi(tr));
+    const double t0 = now_ms();
+    /* Event-driven, as the chunk pipeline: a copy is only handed to the runtime when what it depends on has finished (the
+     * copy engines' queues are in order: a D2H copy queued behind its still-running kernel would hold up the next H2D). */
+    enum { kWaitPack, kComputing, kDownloading, kUnpacking };
+    std::vector<char> state(K, kWaitPack);
+    int next = 0, finished = 0;
+    while (finished < K) {
+        bool progressed = false;
+        if (next < K && packed[next].ready() && (next == 0 || hipEventQuery(w.ev_h2d[next - 1]) == hipSuccess)) {
+            const int k = next++;
+            const long long cnt = soff[k + 1] - soff[k];
+            if (trace) fprintf(stderr, "[hostpipe] %7.3f ms  slice %d packed (frames %lld..%lld of %d utterances, %.1f MB), issuing\n",
+                               now_ms() - t0, k, B[k], B[k + 1], nact[k], cnt * 2 / 1048576.0);
+            /* one stream per job: uploads (after the meta arrays, same stream), kernels (in order: the recursion needs
+             * slice k after slice k - 1), downloads -- a slice's download is never queued behind a later slice's work */
+            HIP_TRY(hipMemcpyAsync(w.in.d + soff[k], h_in + soff[k], (size_t)cnt * sizeof(short), hipMemcpyHostToDevice, sUp));
+            HIP_TRY(hipEventRecord(w.ev_h2d[k], sUp));
+            HIP_TRY(hipStreamWaitEvent(sKern, w.ev_h2d[k], 0));
+            hipStream_t s = sKern;
+            sea::NsBatchArgs a = {};
+            a.in = w.in.d;
+            a.out = w.out.d;
+            a.offsets = w.meta.d + mbase[k];
+            a.lengths = w.meta.d + mbase[k] + nact[k];
+            a.tables = dc->ns;
+            a.n_utt = nact[k];
+            int form;
+            if (K > 1) {
+                a.state = w.d_state;
+                a.resume = k > 0;
+                a.frame_base = (int)B[k];
+                form = (nact[k] <= 4 * dc->n_cu) ? 2 : 4;
+            } else
+                form = ns_pick_form(nact[k], dc->n_cu);
+            if (form == 2 && nact[k] > dc->n_cu) a.prio_row = dc->n_cu;
+            if (ns_launch(a, form, s)) return 1;
+            HIP_TRY(hipEventRecord(w.ev_kernel[k], s));
+            state[k] = kComputing;
+            progressed = true;
+        }
+        for (int k = 0; k < next; ++k) {
+            if (state[k] == kComputing && hipEventQuery(w.ev_kernel[k]) == hipSuccess) {
+                const long long cnt = soff[k + 1] - soff[k];
+                HIP_TRY(hipMemcpyAsync(h_out + soff[k], w.out.d + soff[k], (size_t)cnt * sizeof(short), hipMemcpyDeviceToHost, sDown));
+                HIP_TRY(hipEventRecord(w.ev_done[k], sDown));
+                state[k] = kDownloading;
+                progressed = true;
+                if (trace) fprintf(stderr, "[hostpipe] %7.3f ms  slice %d computed, downloading\n", now_ms() - t0, k);
+            }
+            if (state[k] == kDownloading && hipEventQuery(w.ev_done[k]) == hipSuccess) {
+                if (trace) fprintf(stderr, "[hostpipe] %7.3f ms  slice %d on the host, unpacking\n", now_ms() - t0, k);
+                const long long *offs = w.meta.h + mbase[k], *lens = offs + nact[k];
+                const long long b0 = 80 * B[k];
+                run_copies(0, nact[k], bpre[k].data(), &unpacked[k], &scope.all, small,
+                           [=](int j) { memcpy(out[ix[j]] + b0, h_out + offs[j], (size_t)lens[j] * sizeof(short)); });
+                state[k] = kUnpacking;
+                finished++;
+                progressed = true;
+            }
+        }
+        if (!progressed) {
+            if (next < K && !packed[next].ready()) packed[next].wait_for(std::chrono::microseconds(30));
+            else std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+    }
+    scope.all.wait();
+    if (trace) fprintf(stderr, "[hostpipe] %7.3f ms  all unpacked (%d slices)\n", now_ms() - t0, K);
     scope.ok = true;
     return 0;
 }

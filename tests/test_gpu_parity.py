@@ -282,9 +282,10 @@ def test_resynth_utterances_chunked_by_scratch_budget(oracle, monkeypatch):
 
 def test_denoise_utterances_pipeline_any_chunking(oracle, monkeypatch):
     """sea_denoise_utterances (the host-buffer entry the file driver uses, etsi/cpp/main.cpp:43-67 for a list) is a
-    copy / compute pipeline over chunks of the list (csrc/hostpipe.hip).  Whatever the chunk size and the number of
-    packing threads' tasks, every utterance must equal the oracle and the samples etsi_denoise never writes (the
-    trailing partial frame) must keep the caller's fill."""
+    copy / compute pipeline (csrc/hostpipe.hip): by default over TIME SLICES of the whole list (one launch per slice,
+    the recursion carried in a state blob per utterance), with SEA_HOST_MODE=chunks over chunks of whole utterances.
+    Whatever the number of slices / the chunk size, every utterance must equal the oracle and the samples etsi_denoise
+    never writes (the trailing partial frame) must keep the caller's fill."""
     import ctypes
     import speech_enhancement_amd as sea
     from speech_enhancement_amd import corpus
@@ -306,15 +307,26 @@ def test_denoise_utterances_pipeline_any_chunking(oracle, monkeypatch):
         assert lib.sea_denoise_utterances(pin, po, pl, n) == 0, lib.sea_last_error()
         return outs
 
+    def check(what):
+        for u, (got, w, L) in enumerate(zip(run(), want, lens)):
+            full = L // 80 * 80
+            assert np.array_equal(got[:full], w[:full]), f"{what}: utterance {u} (L={L}) differs"
+            assert np.all(got[full:] == 77), f"{what}: utterance {u}: the trailing partial frame was written"
+
+    for k in (None, "1", "2", "7", "40"):                 # default (4), one launch, and cuts the lengths do not align with
+        if k is None:
+            monkeypatch.delenv("SEA_HOST_SLICES", raising=False)
+        else:
+            monkeypatch.setenv("SEA_HOST_SLICES", k)
+        check(f"{k or 'default'} time slices")
+    monkeypatch.delenv("SEA_HOST_SLICES", raising=False)
+    monkeypatch.setenv("SEA_HOST_MODE", "chunks")
     for mb in ("1", "3", None):
         if mb is None:
             monkeypatch.delenv("SEA_HOST_CHUNK_MB")
         else:
             monkeypatch.setenv("SEA_HOST_CHUNK_MB", mb)
-        for u, (got, w, L) in enumerate(zip(run(), want, lens)):
-            full = L // 80 * 80
-            assert np.array_equal(got[:full], w[:full]), f"chunk {mb} MB: utterance {u} (L={L}) differs"
-            assert np.all(got[full:] == 77), f"chunk {mb} MB: utterance {u}: the trailing partial frame was written"
+        check(f"chunks of {mb} MB")
 
 
 def test_gammatone_filter_vs_oracle(oracle):
