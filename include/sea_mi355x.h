@@ -148,11 +148,13 @@ long long sea_resynth_scratch_bytes(long long total_padded_samples, int n_utt);
  * -------------------------------------------------------------------------------------------- */
 /* Many utterances at once from host memory -- what etsi/cpp/main.cpp:43-67 does per file and the batch tool
  * function/20141106_speech_enhancement/aurora_speech_enhancement/aurora_speech_enhancement.cpp:25-80 from a thread
- * pool.  A copy / compute pipeline (csrc/hostpipe.hip): the list is sorted longest first and cut into chunks of
- * about SEA_HOST_CHUNK_MB (default 12) MB of int16; a pool of SEA_HOST_THREADS (default min(8, cores - 1)) host
- * threads packs chunk k+1 into pinned staging and unpacks chunk k-1 while chunk k's H2D copy, launch and D2H copy
- * run on one of four streams.  out[u][0 .. 80*(lengths[u]/80)) is written, exactly as etsi_denoise does; results
- * do not depend on the cut. */
+ * pool.  A copy / compute pipeline (csrc/hostpipe.hip) over TIME SLICES of the list: slice k = the frames
+ * [B_k, B_k+1) of every utterance that has them (SEA_HOST_SLICES slices of equal sample count, default 8), one launch
+ * per slice with the recursion carried per utterance (sea_ns_denoise_batch_slice); a pool of SEA_HOST_THREADS (default
+ * min(8, cores - 1)) host threads packs slice k+1 into pinned staging and unpacks slice k-1 while slice k's upload,
+ * launch and download run on a stream each.  SEA_HOST_MODE=chunks: chunks of whole utterances of about
+ * SEA_HOST_CHUNK_MB MB instead (default a third of the list).  out[u][0 .. 80*(lengths[u]/80)) is written, exactly as
+ * etsi_denoise does; results do not depend on either cut. */
 int sea_denoise_utterances(const short *const *in, short *const *out, const long *lengths, int n_utt);
 int sea_host_threads(void); /* size of that pool */
 /* NoiseSup + CompCeps from host buffers, the chain ParmInterface.c:275-293 ran before its author commented it out
