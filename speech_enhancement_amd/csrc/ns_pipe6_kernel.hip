@@ -100,7 +100,14 @@ template <bool FD>
 __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
 {
     const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    /* wave -> role (octal digits, wave 0 rightmost; roles 0 FA, 1 FB, 2 B0, 3 N1, 4 G1, 5 S).  This form is for up to two
+     * utterances per CU.  At four per CU (configs[1], where the four-wave form runs at 2.20 ms) the placement of the roles on
+     * the SIMDs decides: identity 3.19 ms, 0104352 (B0, S, N1, G1, FA, FB) 2.78 ms, the ten even / odd splits in wave order
+     * 2.97-3.26 ms (round 3, tools/build_variant.sh -DSEA_NS6_PERM=...): none reaches the four-wave form. */
+#ifndef SEA_NS6_PERM
+#define SEA_NS6_PERM 0543210
+#endif
+    const int role = (SEA_NS6_PERM >> (3 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6))) & 7;
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long off = a.offsets[u];
     const long long nfr = a.lengths[u] / SEA_HOP;
