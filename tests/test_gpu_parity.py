@@ -961,3 +961,26 @@ def test_ns_time_slices_equal_one_launch(oracle):
             if tr["nout"]:
                 f0 = nf[u] - tr["nout"]
                 assert np.array_equal(np.concatenate(outf[u])[f0 * 80: nf[u] * 80].view(np.uint32), tr["den_f32"].view(np.uint32)), f"utterance {u}: float stream"
+
+
+def test_denoise_utterances_one_long_utterance_in_slices(oracle):
+    """A list of ONE two-minute utterance through sea_denoise_utterances: the time-slice pipeline cuts it into eight
+    launches of one workgroup each (a chunk pipeline could not cut it at all); and a list whose short members leave the
+    later slices (720 samples, 79, 0)."""
+    import ctypes
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    _torch()
+    lib = sea.load()
+    for lens in ([16000 * 120 + 37], [16000 * 45, 16000 * 44 + 3, 80 * 9, 79, 0]):
+        utts = [corpus.synth_utterance(400 + i, L) for i, L in enumerate(lens)]
+        outs = [np.full(x.shape, 77, np.int16) for x in utts]
+        n = len(utts)
+        pin = (ctypes.c_void_p * n)(*[x.ctypes.data for x in utts])
+        po = (ctypes.c_void_p * n)(*[y.ctypes.data for y in outs])
+        pl = (ctypes.c_long * n)(*lens)
+        assert lib.sea_denoise_utterances(pin, po, pl, n) == 0, lib.sea_last_error()
+        for x, y, L in zip(utts, outs, lens):
+            full = L // 80 * 80
+            assert np.array_equal(y[:full], oracle.etsi_denoise(x)[:full]), f"L={L}"
+            assert np.all(y[full:] == 77), f"L={L}: the trailing partial frame was written"
