@@ -309,7 +309,7 @@ int sea_afe_features_batch(const float *d_den_f32, const unsigned char *d_flags,
     a.tables = c->cc;
     a.n_utt = n_utt;
     if (total_ceps > 0) {
-        const long long nslot = total_ceps / 16 + n_utt; /* tile slots of 16 frames (cc_kernel.hip, kCcT) */
+        const long long nslot = total_ceps / 8 + n_utt; /* tile slots of 8 frames (cc_kernel.hip, kAfeT) */
         const long long want = nslot < 8192 ? nslot : 8192;
         hipLaunchKernelGGL(sea::afe_ceps_kernel, dim3((unsigned)want), dim3(64), 0, (hipStream_t)stream, a);
         HIP_TRY(hipGetLastError());

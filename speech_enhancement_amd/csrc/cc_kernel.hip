@@ -105,7 +105,10 @@ __global__ __launch_bounds__(64, SEA_RFFT_WAVES) void rfft256_kernel(const float
  * ================================================================================================ */
 namespace {
 
-constexpr int kCcT = 16;
+#ifndef SEA_CC_TILE
+#define SEA_CC_TILE 16
+#endif
+constexpr int kCcT = SEA_CC_TILE;
 
 #ifndef SEA_CC_FASTLOG
 #define SEA_CC_FASTLOG 1
@@ -136,22 +139,22 @@ __device__ __forceinline__ float cc_logf(float v)
 #endif
 }
 
-template <bool SHARED>
+template <bool SHARED, int T = kCcT>
 struct CcGeom {
     /* SHARED: frames of one utterance, 80 samples apart, share their samples; word x of the span (x = 0 is
      * Data[-1] of the tile's first frame) sits at x + x / 80.  Otherwise: kCcT separate frames of 201 floats. */
     static constexpr int FS = SHARED ? 81 : 201;
-    static constexpr int SPAN = SHARED ? 81 * (kCcT - 1) + 204 : 201 * kCcT;
+    static constexpr int SPAN = SHARED ? 81 * (T - 1) + 204 : 201 * T;
 };
 
-template <bool SHARED>
+template <bool SHARED, int T = kCcT>
 struct __attribute__((aligned(16))) CcTileLds {
-    float span[(CcGeom<SHARED>::SPAN + 3) & ~3];
+    float span[(CcGeom<SHARED, T>::SPAN + 3) & ~3];
     float work[512];
     float pw[2][152];                 /* 129 power bins per frame, zeros behind (the mel taps read past 128) */
-    float fb[kCcT][24];
+    float fb[T][24];
     float dctT[SEA_CC_NCHAN * 16];
-    float outb[kCcT * SEA_CC_NCEP];
+    float outb[T * SEA_CC_NCEP];
     float melW[SEA_CC_MELW_LDS ? SEA_CC_TAPS * 32 : 4]; /* [tap][band]: the 22 triangle weights of a band (32 lanes read 32 banks) */
 };
 
@@ -171,8 +174,8 @@ __device__ __forceinline__ int cc_q(int x) /* word offset of Data[x-1] within it
     return SHARED ? x + (x >= 80 ? 1 : 0) + (x >= 160 ? 1 : 0) : x;
 }
 
-template <bool SHARED>
-__device__ __forceinline__ void load_cc_tile_const(CcTileConst &C, CcTileLds<SHARED> &L, const sea_cc_tables *t, int lane)
+template <bool SHARED, int T = kCcT>
+__device__ __forceinline__ void load_cc_tile_const(CcTileConst &C, CcTileLds<SHARED, T> &L, const sea_cc_tables *t, int lane)
 {
     load_fft2_regs<false>(C.fft, &t->fft, lane, nullptr);
 #pragma unroll
@@ -204,16 +207,16 @@ __device__ __forceinline__ void load_cc_tile_const(CcTileConst &C, CcTileLds<SHA
 }
 
 /* the staged tile -> nv rows of 14 coefficients at dst */
-template <bool SHARED>
-__device__ __forceinline__ void cc_tile(CcTileLds<SHARED> &L, const CcTileConst &C, int nv, float *dst, int lane)
+template <bool SHARED, int T = kCcT>
+__device__ __forceinline__ void cc_tile(CcTileLds<SHARED, T> &L, const CcTileConst &C, int nv, float *dst, int lane)
 {
-    constexpr int FS = CcGeom<SHARED>::FS;
+    constexpr int FS = CcGeom<SHARED, T>::FS;
     /* logE (CompCeps.c:413-423): lane f sums the squares of frame f in sample order */
     float logE; /* three ranges of the walk, each with a constant pad */
     {
-        const float *p = L.span + FS * (lane & (kCcT - 1));
+        const float *p = L.span + FS * (lane & (T - 1));
         float acc = 0.0f;
-        if (lane < kCcT) {
+        if (lane < T) {
             if (SHARED) {
 #pragma unroll 8
                 for (int x = 1; x < 80; ++x) { const float v = p[x]; acc += v * v; }
@@ -327,7 +330,10 @@ __global__ __launch_bounds__(64) void compceps_frames_kernel(const float *data20
     }
 }
 
-__global__ __launch_bounds__(64) void compceps_kernel(CepsArgs a)
+#ifndef SEA_CC_MINW
+#define SEA_CC_MINW 1
+#endif
+__global__ __launch_bounds__(64, SEA_CC_MINW) void compceps_kernel(CepsArgs a)
 {
     __shared__ CcTileLds<true> L;
     const int lane = threadIdx.x;
@@ -709,6 +715,14 @@ __device__ __forceinline__ void wp_window(WpLds &W, int slot, float *d, int lane
  * cepstral frames of one utterance as SEPARATE 201-float frames in LDS (WaveProc reshapes each frame in place, so
  * they cannot share samples).  The low-energy check's in-order sum of squares runs lane = frame; the frames that
  * pass go through DoWaveProc one after the other (wave-wide peak search), then the tile through cc_tile(). */
+/* frames per tile of afe_ceps_kernel: 8 (same-box A/B of the feature pass: 16 frames 3.71 ms, 8 frames 3.05 ms -- half the
+ * LDS per wave, 15.6 instead of 25 KB, lets the CU hold the eight waves its registers allow instead of six; compceps_kernel
+ * itself is fastest with 16: 0.715 ms against 0.77-0.79 with 8 and 1.42 with 4) */
+#ifndef SEA_AFE_TILE
+#define SEA_AFE_TILE 8
+#endif
+constexpr int kAfeT = SEA_AFE_TILE;
+
 /* timing-only diagnostic (-DSEA_AFE_TIMING, tools/afe_phases.py): shader clocks workgroup 0 spends per step of a tile */
 #ifdef SEA_AFE_TIMING
 __device__ unsigned long long g_afe_ck[8];
@@ -727,30 +741,33 @@ extern "C" int sea_afe_timing(unsigned long long *out8, int reset)
 #define AFE_CK(k)
 #endif
 
-__global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
+#ifndef SEA_AFE_MINW
+#define SEA_AFE_MINW 1
+#endif
+__global__ __launch_bounds__(64, SEA_AFE_MINW) void afe_ceps_kernel(AfeArgs a)
 {
-    __shared__ CcTileLds<false> L;
+    __shared__ CcTileLds<false, kAfeT> L;
     __shared__ WpLds W;
     const int lane = threadIdx.x;
     CcTileConst C;
-    load_cc_tile_const<false>(C, L, a.tables, lane);
-    const long long nslot = a.ceps_cum[a.n_utt] / kCcT + a.n_utt; /* tile slots as in compceps_kernel */
+    load_cc_tile_const<false, kAfeT>(C, L, a.tables, lane);
+    const long long nslot = a.ceps_cum[a.n_utt] / kAfeT + a.n_utt; /* tile slots as in compceps_kernel */
     for (long long s = blockIdx.x; s < nslot; s += gridDim.x) {
         int lo = 0, hi = a.n_utt;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            if (a.ceps_cum[mid] / kCcT + mid <= s) lo = mid; else hi = mid;
+            if (a.ceps_cum[mid] / kAfeT + mid <= s) lo = mid; else hi = mid;
         }
         const int u = lo;
         const long long c0 = a.ceps_cum[u], cap = a.ceps_cum[u + 1] - c0;
-        const long long j0 = (s - (c0 / kCcT + u)) * kCcT;
+        const long long j0 = (s - (c0 / kAfeT + u)) * kAfeT;
         if (j0 >= cap) continue;
         const int f0 = a.first_out[u];
         const long long nfr = a.lengths[u] / SEA_HOP;
         const long long nout = (f0 >= 0) ? nfr - f0 : 0;
         const long long nceps = (nout >= 3) ? nout - 2 : 0;
         if (j0 == 0 && lane == 0 && a.n_ceps) a.n_ceps[u] = (int)nceps;
-        const int nrow = (int)((cap - j0 < kCcT) ? cap - j0 : kCcT);
+        const int nrow = (int)((cap - j0 < kAfeT) ? cap - j0 : kAfeT);
         long long left = nceps - j0;
         const int nv = (int)(left < 0 ? 0 : (left > nrow ? nrow : left));
         float *dst = a.feat_cc + (c0 + j0) * SEA_CC_NCEP;
@@ -764,7 +781,7 @@ __global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
 #endif
             /* requests in batches before their stores, the outer loop kept rolled (fully unrolled the allocator went to
              * 256 VGPRs + 95 AGPRs, one wave per SIMD: 3.96 -> 5.9 ms) */
-            constexpr int kIter = (kCcT * 201 + kLanes - 1) / kLanes; /* 51 */
+            constexpr int kIter = (kAfeT * 201 + kLanes - 1) / kLanes; /* 51 */
 #pragma unroll 1
             for (int b0 = 0; b0 < kIter; b0 += SEA_AFE_BATCH) {
                 float sv[SEA_AFE_BATCH];
@@ -815,7 +832,7 @@ __global__ __launch_bounds__(64) void afe_ceps_kernel(AfeArgs a)
                 }
 #endif
             wave_sync();
-            cc_tile<false>(L, C, nv, dst, lane);
+            cc_tile<false, kAfeT>(L, C, nv, dst, lane);
             AFE_CK(5);
 #ifdef SEA_AFE_TIMING
             if (blockIdx.x == 0 && threadIdx.x == 0) g_afe_ck[7] += 1;
