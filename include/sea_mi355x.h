@@ -151,7 +151,7 @@ long long sea_resynth_scratch_bytes(long long total_padded_samples, int n_utt);
  * pool.  A copy / compute pipeline (csrc/hostpipe.hip) over TIME SLICES of the list: slice k = the frames
  * [B_k, B_k+1) of every utterance that has them (SEA_HOST_SLICES slices of equal sample count, default 8), one launch
  * per slice with the recursion carried per utterance (sea_ns_denoise_batch_slice); a pool of SEA_HOST_THREADS (default
- * min(8 per device of the node, cores - 1)) host threads packs slice k+1 into pinned staging and unpacks slice k-1 while slice k's upload,
+ * min(8, cores - 1)) host threads packs slice k+1 into pinned staging and unpacks slice k-1 while slice k's upload,
  * launch and download run on a stream each.  SEA_HOST_MODE=chunks: chunks of whole utterances of about
  * SEA_HOST_CHUNK_MB MB instead (default a third of the list).  out[u][0 .. 80*(lengths[u]/80)) is written, exactly as
  * etsi_denoise does; results do not depend on either cut. */

@@ -66,12 +66,9 @@ class Pool {
     {
         int n = 0;
         if (const char *e = getenv("SEA_HOST_THREADS")) n = atoi(e);
-        if (n <= 0) { /* eight per device of the node (one device keeps them busy: DESIGN 6.1), within the cores there are */
+        if (n <= 0) {
             const unsigned hw = std::thread::hardware_concurrency();
-            int ndev = 0;
-            if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
-            const unsigned want = (unsigned)std::min(8 * ndev, 64);
-            n = hw > 2 ? (int)std::min(want, hw - 1) : 1;
+            n = hw > 2 ? (int)std::min(8u, hw - 1) : 1;
         }
         for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
     }
