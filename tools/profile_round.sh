@@ -16,12 +16,12 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_tr
 # every profiler pass prints a line first (a silent call is taken to be hung after 7 minutes) and runs under its own limit:
 # a pass that hangs ends the script -- no further GPU step after a timeout
-pass() { echo "profile_round: $1"; shift; timeout -k 10 240 "$@" || { echo "profile_round: that pass failed or timed out: stopping"; exit 1; }; }
-pass "kernel trace" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_tr -- python3 $R/bench.py --steps 10 --no-cpu-baseline --no-end-to-end > /tmp/p_tr.log 2>&1
+pass() { timeout -k 10 240 "$@" || { echo "profile_round: that pass failed or timed out: stopping" >&2; exit 1; }; }
+echo "profile_round: kernel trace"; pass rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_tr -- python3 $R/bench.py --steps 10 --no-cpu-baseline --no-end-to-end > /tmp/p_tr.log 2>&1
 python3 $R/tools/prof_summary.py /tmp/p_tr $O/${TAG}_kernel_trace_stats.txt --delete-raw > /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/p_$c
-  pass "pmc $c" rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -- python3 $R/bench.py --steps 3 --warmup 1 --also-steps 2 --no-cpu-baseline --no-end-to-end --no-configs4 > /tmp/p_$c.log 2>&1
+  echo "profile_round: pmc $c"; pass rocprofv3 --pmc $c --output-format csv -d /tmp/p_$c -- python3 $R/bench.py --steps 3 --warmup 1 --also-steps 2 --no-cpu-baseline --no-end-to-end --no-configs4 > /tmp/p_$c.log 2>&1
   python3 $R/tools/prof_summary.py /tmp/p_$c $O/${TAG}_pmc_$(echo $c | tr A-Z a-z | sed s/_size//).txt --delete-raw > /dev/null
 done
 i=0
@@ -29,12 +29,12 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
   rm -rf /tmp/p_sq$i
-  pass "pmc SQ set $i" rocprofv3 --pmc $set --output-format csv -d /tmp/p_sq$i -- python3 $R/bench.py --steps 3 --warmup 1 --also-steps 2 --no-cpu-baseline --no-end-to-end --no-configs4 > /tmp/p_sq$i.log 2>&1
+  echo "profile_round: pmc SQ set $i"; pass rocprofv3 --pmc $set --output-format csv -d /tmp/p_sq$i -- python3 $R/bench.py --steps 3 --warmup 1 --also-steps 2 --no-cpu-baseline --no-end-to-end --no-configs4 > /tmp/p_sq$i.log 2>&1
   python3 $R/tools/prof_summary.py /tmp/p_sq$i $O/${TAG}_pmc_sq$i.txt --delete-raw > /dev/null
 done
 # dynamic instruction mix of the headline kernel (prices its vector-issue time: roofline.valu_issue_frac)
 rm -rf /tmp/p_mix1
-pass "pmc instruction mix" rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 \
+echo "profile_round: pmc instruction mix"; pass rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 \
     --output-format csv -d /tmp/p_mix1 -- python3 $R/bench.py --steps 3 --warmup 1 --no-also --no-cpu-baseline > /tmp/p_mix1.log 2>&1
 python3 $R/tools/prof_summary.py /tmp/p_mix1 $O/${TAG}_pmc_mix1.txt --delete-raw > /dev/null
 python3 $R/tools/make_pmc_traffic.py $O/${TAG}_pmc_fetch.txt $O/${TAG}_pmc_write.txt $O/pmc_traffic.json $O/${TAG}_pmc_sq1.txt $O/${TAG}_pmc_mix1.txt && cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
