@@ -89,7 +89,9 @@ def test_ns16k_streams_vs_oracle_chunked(oracle):
 
 def test_ns16k_golden_no_oracle_in_the_loop():
     """The HIP path against the committed fixture tests/golden/ns16k_golden.npz (written by the restatement: a regression
-    anchor, see oracle/gen_golden.py)."""
+    anchor, see oracle/gen_golden.py).  The transform's twiddles are the HOST libm's cosf / sinf (the C++ float overloads
+    of aurora_etsi/rfft.cpp), computed where the library is initialised: only if the fixture does not match is the
+    oracle consulted, to tell a libm that rounds a twiddle differently than the fixture's host from a real mismatch."""
     import speech_enhancement_amd as sea
     torch = _torch()
     g = np.load(os.path.join(GOLD, "ns16k_golden.npz"))
@@ -99,7 +101,13 @@ def test_ns16k_golden_no_oracle_in_the_loop():
         r = sea.ns16k_streams_push(torch.from_numpy(x[: n * 160].reshape(1, n, 160)).cuda())
         got = {k: v.cpu().numpy()[0] for k, v in r.items() if k != "state"}
         want = {k: g[f"{name}/{k}"] for k in ("out", "var", "spec", "mel", "vadns", "counter", "wiener")}
-        _compare(got, want, n, name)
+        try:
+            _compare(got, want, n, name)
+        except AssertionError:
+            from oracle import oracle as O
+            live = O.Oracle().ns16k_new().push(x)
+            _compare(got, live, n, name + " (live oracle)")          # a real mismatch fails here
+            pytest.skip("this host's cosf / sinf differ from the fixture's host: HIP == live oracle, fixture not comparable")
 
 
 def test_etsi_denoise_mapping_symbols_16k_native(oracle, tmp_path):
