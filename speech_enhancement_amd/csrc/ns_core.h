@@ -691,13 +691,9 @@ __device__ __forceinline__ int fd_var(NsFd &d, const float *W, int fc)
     return fd_var_sums<N>(d, uniform_f(mean), uniform_f(var), fc);
 }
 
-/* SpeechQSpec + SpeechQMel on the 25 mel-filtered gains (in LDS); returns spec | mel << 1 */
-__device__ __forceinline__ int fd_spec_mel(NsFd &d, const float *mel, int fc)
+/* SpeechQSpec + SpeechQMel given the in-order sum of the 25 mel-filtered gains and gains 1..3; returns spec | mel << 1 */
+__device__ __forceinline__ int fd_spec_mel_sums(NsFd &d, float tempEn, float m1, float m2, float m3, int fc)
 {
-    float tempEn = 0.0f;
-#pragma unroll
-    for (int i = 0; i < SEA_NMEL; ++i) tempEn += mel[i];
-    tempEn = uniform_f(tempEn);
     d.specValues = (float)((double)(tempEn * tempEn) - 3.0);
     if (fc == 1) d.specMean = d.specValues;
     if (fc < 15) {
@@ -712,7 +708,7 @@ __device__ __forceinline__ int fd_spec_mel(NsFd &d, const float *mel, int fc)
         d.specMean = (float)((double)d.specMean * 0.97 + (double)d.specValues * 0.03);
     const int spec = ((double)d.specValues > (double)d.specMean * 1.65) ? 1 : 0;
 
-    const float mel1 = (float)((double)(float)(mel[1] + mel[2] + mel[3]) / 3.0);
+    const float mel1 = (float)((double)(float)(m1 + m2 + m3) / 3.0);
     const float smoothMel = (float)(0.75 * (double)mel1 + 0.25 * (double)d.mel0);
     d.mel0 = mel1;
     if (fc < 15) d.melMean = (d.melMean > smoothMel) ? d.melMean : smoothMel;
@@ -722,6 +718,21 @@ __device__ __forceinline__ int fd_spec_mel(NsFd &d, const float *mel, int fc)
     const int melf = ((double)smoothMel > (double)d.melMean * 3.25) ? 1 : 0;
     return spec | (melf << 1);
 }
+
+/* SpeechQSpec + SpeechQMel on the 25 mel-filtered gains (in LDS); returns spec | mel << 1 */
+__device__ __forceinline__ int fd_spec_mel(NsFd &d, const float *mel, int fc)
+{
+    float tempEn = 0.0f;
+#pragma unroll
+    for (int i = 0; i < SEA_NMEL; ++i) tempEn += mel[i];
+    return fd_spec_mel_sums(d, uniform_f(tempEn), mel[1], mel[2], mel[3], fc);
+}
+
+/* What ns_back leaves in fdRec for the DEFERRED evaluation of the speech measures (four-wave fd kernel: their three
+ * in-order sums ride in free lanes of the helper wave's chain, their scalar logic runs in the transform wave):
+ * [0..63] the first 64 Wiener gains, [64..127] their squares, [128..152] the 25 mel-filtered gains, [153..155] zeros,
+ * ints [156] the frame counter narrowed to int16, [157] nbSpeechFrames > 4 */
+constexpr int kFdRecFloats = 160;
 
 /* FRONT half of a stage: analysis window on buf[60..259] (buf = 320-sample stage buffer, zero
  * padded to 256: NoiseSup.c:218-231), 256-point rfft, FFTtoPSD (129 power bins averaged pairwise to
@@ -1087,7 +1098,7 @@ template <int ST, bool PIPE, bool FD = false, bool DEFER_FIR = false, bool RL = 
 __device__ __forceinline__ void ns_back(const float *psd, const float *buf, BackLds &B, NsRegs &s,
                                         const NsConst &C, float *dst, int lane, float frameEnExt = 0.0f,
                                         float *spectOut = nullptr, const float *idctLds = nullptr,
-                                        NsFd *fd = nullptr, int *fdFlags = nullptr)
+                                        NsFd *fd = nullptr, int *fdFlags = nullptr, float *fdRec = nullptr)
 {
     NS_BACK_CK_START;
     const float nSigLo = psd[lane], nSigHi = psd[64];
@@ -1176,6 +1187,10 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     NS_BACK_CK(0); /* PSD mean, VAD update, FilterCalc of 65 bins */
     B.wbuf[lane] = WLo;
     if (lane == 0) B.wbuf[64] = WHi;
+    if (FD && ST == 0 && fdRec) { /* deferred speech measures (kFdRecFloats) */
+        fdRec[lane] = WLo;
+        fdRec[64 + lane] = WLo * WLo;
+    }
     if (PIPE && ST == 0) { /* the helper wave sums denSigSE1 */
         spectOut[lane] = s.denLo[0];
         if (lane == 0) spectOut[64] = s.denHi[0];
@@ -1186,13 +1201,19 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     wave_sync();
 
     int fdBits = 0;
-    if (FD && ST == 0) fdBits = fd_var(*fd, B.wbuf, nb16); /* NoiseSup.c:1255-1258, before DoMelFB */
+    if (FD && ST == 0 && !fdRec) fdBits = fd_var(*fd, B.wbuf, nb16); /* NoiseSup.c:1255-1258, before DoMelFB */
 
     NS_BACK_CK(1); /* gains staged in LDS */
     float melOut = ns_mel_fb(B, C, lane);
     NS_BACK_CK(2); /* mel filter bank */
 
-    if (FD && ST == 0) { /* NoiseSup.c:1268-1281, on the mel-filtered gains; VADNS :1359-1365 */
+    if (FD && ST == 0 && fdRec) {
+        if (lane < SEA_NMEL) fdRec[128 + lane] = melOut;
+        if (lane == 0) {
+            reinterpret_cast<int *>(fdRec)[156] = nb16;
+            reinterpret_cast<int *>(fdRec)[157] = (s.nbSpeech > 4) ? 1 : 0;
+        }
+    } else if (FD && ST == 0) { /* NoiseSup.c:1268-1281, on the mel-filtered gains; VADNS :1359-1365 */
         if (lane < SEA_NMEL) B.mel[lane] = melOut;
         wave_sync();
         fdBits |= fd_spec_mel(*fd, B.mel, nb16) << 1;
@@ -1397,16 +1418,23 @@ __device__ __forceinline__ bool dc_step_ok(float d, float yPrev)
 /* *unsafe (optional): set when some step of the DC chain fails dc_step_ok -- checked by the sixteen recomputing lanes
  * on the values they hold in registers (start value, five inputs, five outputs); the caller then redoes the frame on
  * the exact path (dc_redo_exact).  nullptr: the caller verifies through LDS (dc_verify). */
-template <int CHUNKS>
+/* FDCH (four-wave fd kernel): three more sums in lanes 48..50, which otherwise repeat the DC chain -- the mean and the
+ * sum of squares of the first 64 Wiener gains (SpeechQVar) and the sum of the 25 mel-filtered gains (SpeechQSpec) of
+ * the frame whose record fdRec is (kFdRecFloats); returned in fdSums[0..2]. */
+template <int CHUNKS, bool FDCH = false>
 __device__ __forceinline__ void helper_chains(const float *sq, const float *den, const float *dif, float *out,
                                               const float *zero4, float &vadSum, float &denSum,
-                                              float &y, int lane, bool *unsafe = nullptr)
+                                              float &y, int lane, bool *unsafe = nullptr, const float *fdRec = nullptr,
+                                              float *fdSums = nullptr)
 {
     const int g = lane >> 4;
+    const bool fdLane = FDCH && lane >= 48 && lane <= 50;
     const float *src = (g == 0) ? sq : ((g == 1) ? den : dif);
+    if (FDCH && fdLane) src = fdRec + 64 * (lane - 48);
     const float *tail = (g == 1) ? zero4 : src; /* the den chain runs out after 65 terms: x = 0 from n = 68 on */
-    const float m = (g >= 2) ? 0.9990234375f : 1.0f;
-    float acc = (g == 0) ? 64.0f : ((g == 1) ? 0.0f : y);
+    const int fdLim = FDCH ? ((lane == 50) ? 28 : (fdLane ? 64 : SEA_HOP)) : SEA_HOP; /* an fd chain's first quad of zeros */
+    const float m = (g >= 2 && !fdLane) ? 0.9990234375f : 1.0f;
+    float acc = (g == 0) ? 64.0f : ((g == 1 || fdLane) ? 0.0f : y);
     /* the 20 quads are requested in CHUNKS chunks (4: 2 x 20 VGPRs in flight; 10: 2 x 8, for the 80-VGPR kernel
      * forms), chunk c + 1 before the chain of chunk c starts (an LDS round trip is ~60 clk) */
     constexpr int kQ = SEA_HOP / 4 / CHUNKS;
@@ -1416,7 +1444,9 @@ __device__ __forceinline__ void helper_chains(const float *sq, const float *den,
 #pragma unroll
         for (int k = 0; k < kQ; ++k) {
             const int n = 4 * (c * kQ + k);
-            dstq[k] = *reinterpret_cast<const float4 *>((n >= 68) ? tail + ((g == 1) ? 0 : n) : src + n);
+            const float *p = (n >= 68) ? tail + ((g == 1) ? 0 : n) : src + n;
+            if (FDCH && n >= 28) p = (n >= fdLim) ? zero4 : p;
+            dstq[k] = *reinterpret_cast<const float4 *>(p);
         }
     };
     /* the segment inputs of the recomputing lanes (stride 5 floats across 16 lanes: 16 different banks) */
@@ -1467,6 +1497,11 @@ __device__ __forceinline__ void helper_chains(const float *sq, const float *den,
     vadSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 0));
     denSum = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 16));
     y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 32));
+    if (FDCH && fdSums) {
+        fdSums[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 48));
+        fdSums[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 49));
+        fdSums[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 50));
+    }
     wave_sync();
 }
 

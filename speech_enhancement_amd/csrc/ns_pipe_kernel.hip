@@ -142,6 +142,10 @@ struct __attribute__((aligned(16))) Rec12 { /* B0 -> F, S */
     float den[68]; /* denSigSE1 of this tick, summed in order by S */
     int valid, tick, pad0, pad1;
 };
+struct __attribute__((aligned(16))) RecFd { /* S -> F, same variant: the measures' three sums of the frame S summed at this beat */
+    float mean, var, tempEn, m1, m2, m3;
+    int nb16, vadns, tick, pad0, pad1, pad2; /* tick 0: the first stage did not run */
+};
 struct __attribute__((aligned(16))) Rec23 { /* F -> B1 */
     float psd[68];
     int valid, tick, pad0, pad1;
@@ -154,7 +158,7 @@ struct __attribute__((aligned(16))) Rec34 { /* B1 -> F -> S */
     int produced, tick, pad1, pad2;
 };
 
-template <bool ADDR_LDS>
+template <bool ADDR_LDS, bool FD = false>
 struct __attribute__((aligned(16))) PipeLds {
     float circ[2][kCirc + kMirror]; /* stage-0 / stage-1 sample buffers */
     float work[512];                /* the two FFT frames of F */
@@ -172,6 +176,10 @@ struct __attribute__((aligned(16))) PipeLds {
     Rec12 r12[2];
     Rec23 r23[2];
     Rec34 r34[kRec34];
+    /* frame-dropping VAD variant only, BEHIND everything else (the other forms keep their layout): what B0 leaves of frame f
+     * (by parity) for the speech measures (ns_core.h, kFdRecFloats), and their sums on the way from S to F */
+    float fdRec[2][FD ? kFdRecFloats : 4];
+    RecFd rfd[FD ? 2 : 1];
 };
 
 /* start of the 320-sample window "buf[0..319]" of the reference at tick t: buf[240..319] is the
@@ -211,7 +219,7 @@ __device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables 
 }
 
 template <bool FD, bool ADDR_LDS, bool SLICES = false>
-__device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_LDS> &L)
+__device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_LDS, FD> &L)
 {
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -254,6 +262,10 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
         L.r23[threadIdx.x].valid = 0;
     }
     if (threadIdx.x < kRec34) L.r34[threadIdx.x].produced = 0;
+    if (FD && threadIdx.x < 2) {
+        L.rfd[threadIdx.x].tick = 0;
+        L.fdRec[threadIdx.x][153] = L.fdRec[threadIdx.x][154] = L.fdRec[threadIdx.x][155] = 0.0f; /* the mel chain's zeros */
+    }
     block_sync();
 
     NS_T_DECL;
@@ -280,6 +292,8 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
          * transform's window loads at the top of the next one no longer wait for these LDS stores.
          * (valid, tick) of frames i, i-1, i-2 stay in registers: B0 only copies them from Rec01 to Rec12. */
         int vCur = 0, tCur = 0, v1 = 0, t1 = 0, v2 = 0, t2 = 0;
+        NsFd fdF; /* FD: the frame-dropping VAD's measures (SpeechQVar / Spec / Mel) live here */
+        fd_init(fdF);
         auto intake = [&](long long f) {
             /* the 80-VGPR form has no register left for the lane id across the transform: the allocator would park it
              * (and 8 * lane) in scratch and reload both every frame; two v_mbcnt recompute it instead */
@@ -362,6 +376,19 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                     if (g.produced) ns_idct_tail<SEA_IDCT_SPLIT>(g.mel, L.idctT, irWin, g.fir, lane);
                 }
             }
+            if (FD) { /* the scalar logic of the speech measures of the frame whose sums S finished one beat ago */
+                const long long ff = i - 3;
+                if (ff >= 0 && ff < nfr) {
+                    const RecFd &q = L.rfd[ff & 1];
+                    const int tf = q.tick;
+                    if (tf > 0) {
+                        int bits = fd_var_sums<64>(fdF, uniform_f(q.mean), uniform_f(q.var), q.nb16);
+                        bits |= fd_spec_mel_sums(fdF, uniform_f(q.tempEn), q.m1, q.m2, q.m3, q.nb16) << 1;
+                        bits |= q.vadns ? 8 : 0;
+                        if (lane == 0) L.fdFlags[tf & (kSlots - 1)] = bits; /* bit 0 Var, 1 Spec, 2 Mel, 3 VADNS */
+                    }
+                }
+            }
             v2 = v1, t2 = t1, v1 = vCur, t1 = tCur;
             vCur = 0;
             if (i + 1 < nfr) intake(i + 1);
@@ -414,9 +441,11 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                     int bits = 0;
                     /* the helper wave leaves the frame's in-order sum of squares; the log-energy (NoiseSup.c:391) is taken
                      * here, by its consumer: this wave has ~1000 clk of slack per frame, the helper wave none */
+                    /* FD: the speech measures' inputs go into o.fd; S sums them in free lanes of its chain one beat later, F
+                     * runs their scalar logic the beat after (this wave has no slack left for ~1300 clk of them) */
                     ns_back<0, true, FD, false, !ADDR_LDS>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
-                                         vad_frame_energy(L.frameEn[t & (kSlots - 1)]), o.den, L.idctT, &fd, &bits);
-                    if (FD && lane == 0) L.fdFlags[t & (kSlots - 1)] = bits;
+                                         vad_frame_energy(L.frameEn[t & (kSlots - 1)]), o.den, L.idctT, &fd, &bits,
+                                         FD ? L.fdRec[f & 1] : nullptr);
                     if (lane < 40) {
                         const float2 v = *reinterpret_cast<const float2 *>(tmp + 2 * lane);
                         slot_store(L.circ[1], t, lane, v.x, v.y);
@@ -511,6 +540,8 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
             bool doVad = false, doDen = false, produced = false;
             int tp = 0, td = 0;
             const float *denSrc = L.r12[0].den;
+            const float *fdSrc = L.fdRec[0];
+            float fdSums[3] = {0.0f, 0.0f, 0.0f};
             if (fp >= 0 && fp < nfr) {
                 const Rec01 &r = L.r01[fp & 1];
                 doVad = (SEA_ROLE_MASK & 16) && r.valid;
@@ -521,6 +552,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                 doDen = (SEA_ROLE_MASK & 32) && r.valid && r.tick >= 3;
                 td = r.tick;
                 denSrc = r.den;
+                fdSrc = L.fdRec[fd & 1];
             }
             const bool haveOut = fo >= 0 && fo < nfr;
             float *soutS = L.sout[SEA_STORE_IN_F ? (fo & 1) : 0];
@@ -557,17 +589,31 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                 if (produced && SEA_FIR_IN_S && lane < 40) *reinterpret_cast<float2 *>(&L.sdif[2 * lane]) = make_float2(d0, d1);
             }
             NS_T_CK(0);
+            if (FD && fd >= 0 && fd < nfr && !doDen && lane == 0) L.rfd[fd & 1].tick = 0;
             if (doVad || doDen || produced) {
                 wave_sync();
                 float vadSum, denTotal, y = dcY;
                 if (SEA_ABL_S & 8) {
                     vadSum = L.ssq[3] + 64.0f, denTotal = denSrc[5], y = L.sdif[7];
                 } else
-                    helper_chains<ADDR_LDS ? 10 : 4>(L.ssq, denSrc, L.sdif, soutS, L.szero, vadSum, denTotal, y, lane);
+                    helper_chains<ADDR_LDS ? 10 : 4, FD>(L.ssq, denSrc, L.sdif, soutS, L.szero, vadSum, denTotal, y, lane, nullptr,
+                                                         FD ? fdSrc : nullptr, FD ? fdSums : nullptr);
                 NS_T_CK(1);
                 if (doVad && lane == 0) L.frameEn[(tp + 2) & (kSlots - 1)] = vadSum; /* 64 + sum of squares; B0 takes the log */
                 NS_T_CK(2);
                 if (doDen && lane == 0) L.denSum[td & (kSlots - 1)] = denTotal;
+                if (FD && doDen && lane == 0) { /* hand the measures' sums of that frame to F */
+                    RecFd &q = L.rfd[fd & 1];
+                    q.mean = fdSums[0];
+                    q.var = fdSums[1];
+                    q.tempEn = fdSums[2];
+                    q.m1 = fdSrc[129];
+                    q.m2 = fdSrc[130];
+                    q.m3 = fdSrc[131];
+                    q.nb16 = reinterpret_cast<const int *>(fdSrc)[156];
+                    q.vadns = reinterpret_cast<const int *>(fdSrc)[157];
+                    q.tick = td;
+                }
                 if (produced) {
                     /* (checking the recurrence's exactness condition on the sixteen recomputing lanes' registers instead
                      * was measured slower: five checks in a row per lane against two per lane here) */
@@ -658,7 +704,7 @@ __global__ __launch_bounds__(256, SEA_NS_BIG_WAVES) void ns_denoise_pipe_big_sli
  * B0 and their four bits stored per output frame: input of the frame-dropping VAD */
 __global__ __launch_bounds__(256, SEA_NS_MIN_WAVES) void ns_denoise_pipe_fd_kernel(NsBatchArgs a)
 {
-    __shared__ p4::PipeLds<false> L;
+    __shared__ p4::PipeLds<false, true> L;
     p4::ns_pipe_body<true, false>(a, L);
 }
 #endif
