@@ -242,8 +242,9 @@ void sea_ns16k_fft_host(float *x512);
  * resyth_64sub_ori/cpp/aurora_etsi_test.cpp:20) they run the 16 k-native variant the reference builds behind these
  * names: one call consumes dataNum / 160 frames, zero frames are skipped (aurora_etsi/NoiseSup.cpp:1160-1171), and
  * the FILE* argument of func_Wiener, when not NULL, receives the line of 25 gains per second-stage frame (:1319-1328).
- * Extension: sm_glb_res pointing to {int SamplingFrequency = 8000} (DENOISEGlobalImpl, NoiseSupExports.h:9-12) selects
- * the etsi/ arithmetic on 80-sample frames instead (sea_ns_streams_push_fd; nothing is printed).
+ * sm_glb_res is ignored whatever it points to, as the reference ignores it (NoiseSup.cpp:913-922).  Extension, opt-in
+ * through the environment only: SEA_MAPPING_8K=1 at global_init selects the etsi/ arithmetic on 80-sample frames
+ * instead (sea_ns_streams_push_fd; nothing is printed).
  * global_init / thread_init return 1 on success, func_Wiener / func return 0. */
 int etsi_denoise_mapping_global_init(void **sm_glb_pins, void *sm_glb_res);
 int etsi_denoise_mapping_thread_init(void **sm_thd_pins, void *sm_glb_ins);
@@ -288,6 +289,9 @@ int sea_selftest_log(const float *x, double *ln_out, int n);
 int sea_selftest_log_dd(const double *x, double *hi, double *lo, int n);
 int sea_selftest_log_sites(const float *x, float *site1, float *site2, int n);
 int sea_selftest_log_guard(int site, unsigned long long *stats8, float *hits3, int cap);
+/* host pipelines (csrc/hostpipe.hip): from the nth hipEventQuery of the process on, every query reports a device fault
+ * (0: off).  The pipelines must then return 1 -- the reference's fault code -- instead of polling for ever. */
+int sea_selftest_hostpipe_fault(long long nth_query);
 
 #ifdef __cplusplus
 }

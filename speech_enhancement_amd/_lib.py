@@ -74,6 +74,7 @@ PROTOTYPES = {
     "sea_selftest_log_dd": (_i, [_vp, _vp, _vp, _i]),
     "sea_selftest_log_sites": (_i, [_vp, _vp, _vp, _i]),
     "sea_selftest_log_guard": (_i, [_i, _vp, _vp, _i]),
+    "sea_selftest_hostpipe_fault": (_i, [ctypes.c_longlong]),
 }
 
 _lib = None

@@ -20,7 +20,7 @@
  * SEA_HOST_MODE=chunks: the pieces are chunks of whole utterances, sorted longest first, one launch per chunk on its own
  * part of ONE device buffer.  Results do not depend on either cut.
  * Staging, device buffers, streams and events are grow-only and belong to the calling host thread (the reference's
- * batch tool calls etsi_denoise from N threads); the packing threads are one process-wide pool.
+ * batch tool calls etsi_denoise from N threads); the packing threads are one pool per device.
  */
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -44,12 +44,23 @@ using namespace sea_capi;
 namespace {
 
 /* ---- packing threads ------------------------------------------------------------------------------ */
+/* One pool PER DEVICE (round 4): one device keeps eight packing threads busy, so a process-wide pool of
+ * eight capped the file drivers' device threads at one device's worth of packing on an 8-GPU node.  A pool is created by
+ * the first host thread that runs a pipeline on that device -- never from a static constructor, and without a HIP call:
+ * the device index comes from the caller's PipeWs -- and host threads that share a device (SEA_DEVICES=3 on one GPU) share
+ * its pool.  SEA_HOST_THREADS = threads per device (default min(8, (cores - 1) / devices in use so far), at least 2). */
 class Pool {
   public:
-    static Pool &get()
+    static constexpr int kMaxDev = 64;
+    static Pool &get(int device)
     {
-        static Pool p;
-        return p;
+        static std::mutex m;
+        static Pool *pools[kMaxDev] = {};
+        static int n_pools = 0;
+        const int d = (device >= 0 && device < kMaxDev) ? device : 0;
+        std::lock_guard<std::mutex> lk(m);
+        if (!pools[d]) pools[d] = new Pool(++n_pools); /* lives until process exit: its threads block on the queue */
+        return *pools[d];
     }
     int size() const { return (int)th_.size(); }
     void submit(std::function<void()> f)
@@ -62,13 +73,13 @@ class Pool {
     }
 
   private:
-    Pool()
+    explicit Pool(int n_pools_now)
     {
         int n = 0;
         if (const char *e = getenv("SEA_HOST_THREADS")) n = atoi(e);
         if (n <= 0) {
             const unsigned hw = std::thread::hardware_concurrency();
-            n = hw > 2 ? (int)std::min(8u, hw - 1) : 1;
+            n = hw > 2 ? (int)std::min(8u, std::max(2u, (hw - 1) / (unsigned)n_pools_now)) : 1;
         }
         for (int i = 0; i < n; ++i) th_.emplace_back([this] { run(); });
     }
@@ -184,7 +195,7 @@ struct Latch {
 
 /* copies [j0, j1) of a job list on the pool (or inline when the job is small), cut into ~1 MB tasks */
 template <class Copy>
-void run_copies(int j0, int j1, const long long *bytes_prefix, Latch *chunk, Latch *all, bool inline_, Copy copy)
+void run_copies(Pool &pool, int j0, int j1, const long long *bytes_prefix, Latch *chunk, Latch *all, bool inline_, Copy copy)
 {
     if (j0 >= j1) return;
     if (inline_) {
@@ -199,7 +210,7 @@ void run_copies(int j0, int j1, const long long *bytes_prefix, Latch *chunk, Lat
         while (b < j1 && bytes_prefix[b] - bytes_prefix[a] < kTask) ++b;
         chunk->add(1);
         all->add(1);
-        Pool::get().submit([=] {
+        pool.submit([=] {
             for (int j = a; j < b; ++j) copy(j);
             copy_fence(); /* non-temporal stores are visible to the copy engine / the caller before the task counts as done */
             chunk->done();
@@ -254,6 +265,8 @@ struct PipeWs {
     Grow<short> in, out;
     Grow<float> mask;      /* resynth: mask rows */
     Grow<long long> meta;  /* offsets | lengths | mask offsets, in launch order */
+    Grow<float> f32, ceps; /* sea_denoise_ceps_utterances: the float NoiseSup stream (device side used only), the cepstra */
+    Grow<int> ints;        /* the same: first_out | n_ceps | order */
     float *d_inter = nullptr; /* resynth scratch */
     size_t inter_bytes = 0;
     float *d_state = nullptr; /* NoiseSup in time slices: the recursion per utterance between two launches */
@@ -271,6 +284,9 @@ struct PipeWs {
         out.release();
         mask.release();
         meta.release();
+        f32.release();
+        ceps.release();
+        ints.release();
         if (d_inter) (void)hipFree(d_inter);
         d_inter = nullptr;
         inter_bytes = 0;
@@ -360,6 +376,28 @@ struct Scope {
     }
 };
 
+/* hipEventQuery as a three-way answer: 0 and *done set when the event has completed, 0 and *done clear while the work
+ * before it is still running (hipErrorNotReady), 1 after fail() for ANYTHING else -- a failed kernel or copy, an invalid
+ * event.  The pipelines below poll events; treating every non-success as "not yet" would spin for ever on a fault instead
+ * of returning the reference's fault code.  `query` is hipEventQuery except in the state-machine unit test. */
+typedef hipError_t (*EventQueryFn)(hipEvent_t);
+EventQueryFn g_event_query = hipEventQuery;
+int ev_ready(hipEvent_t e, bool *done, const char *what)
+{
+    const hipError_t r = g_event_query(e);
+    *done = (r == hipSuccess);
+    if (r == hipSuccess || r == hipErrorNotReady) return 0;
+    (void)hipGetLastError(); /* the sticky copy of an asynchronous fault must not fail the caller's next, unrelated call */
+    return fail("%s: %s", what, hipGetErrorString(r));
+}
+/* 1 done, 0 still running, -1 failed (fail() has the message) */
+int evq(hipEvent_t e, const char *what)
+{
+    bool done = false;
+    if (ev_ready(e, &done, what)) return -1;
+    return done ? 1 : 0;
+}
+
 double now_ms()
 {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -396,7 +434,30 @@ std::vector<int> cut_chunks(const std::vector<long long> &weight_prefix, int n, 
 
 extern "C" {
 
-int sea_host_threads(void) { return Pool::get().size(); }
+/* Test hook: from the nth event query of this process on (1-based; 0 switches the hook off) every query reports a device
+ * fault instead of asking the runtime.  tests/test_gpu_parity.py::test_host_pipeline_returns_fault_on_event_error checks
+ * that all three pipelines then return 1 with their streams drained and work again afterwards. */
+static std::atomic<long long> g_fault_after{0}, g_queries{0};
+static hipError_t faulty_query(hipEvent_t e)
+{
+    const long long n = g_fault_after.load();
+    if (n > 0 && ++g_queries >= n) return hipErrorLaunchFailure;
+    return hipEventQuery(e);
+}
+int sea_selftest_hostpipe_fault(long long nth_query)
+{
+    g_queries = 0;
+    g_fault_after = nth_query;
+    g_event_query = nth_query > 0 ? faulty_query : hipEventQuery;
+    return 0;
+}
+
+int sea_host_threads(void)
+{ /* of the calling thread's current device */
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return Pool::get(dev).size();
+}
 
 /* ---------------------------------------------------------------------------------------------------- */
 static int denoise_utterances_slices(const short *const *in, short *const *out, const long *lengths, int n_utt);
@@ -421,6 +482,7 @@ static int denoise_utterances_chunks(const short *const *in, short *const *out, 
 
     PipeWs &w = t_ws;
     HIP_TRY(w.bind());
+    Pool &pool = Pool::get(w.device);
     HIP_TRY(w.in.ensure((size_t)total));
     HIP_TRY(w.out.ensure((size_t)total));
     HIP_TRY(w.meta.ensure(2 * (size_t)n_utt));
@@ -436,7 +498,7 @@ static int denoise_utterances_chunks(const short *const *in, short *const *out, 
      * 16 chunks 16.5 ms; one chunk = no overlap 10.4 ms).  SEA_HOST_CHUNK_MB sets the chunk size in MB of int16. */
     const long long chunk_samples = getenv("SEA_HOST_CHUNK_MB") ? env_mb("SEA_HOST_CHUNK_MB", 24) * (1 << 20) / 2
                                                                 : std::max<long long>((total + 2) / 3, 1 << 20);
-    const bool small = total * 2 < (2 << 20) || n_utt == 1 || Pool::get().size() <= 1;
+    const bool small = total * 2 < (2 << 20) || n_utt == 1 || pool.size() <= 1;
     const std::vector<int> cuts = small ? std::vector<int>{0, n_utt} : cut_chunks(pre, n_utt, chunk_samples, kMaxChunks);
     const int nchunk = (int)cuts.size() - 1;
     const int form = ns_pick_form(n_utt, dc->n_cu);
@@ -466,7 +528,7 @@ static int denoise_utterances_chunks(const short *const *in, short *const *out, 
     const int *ix = idx.data();
     for (int i = 0; i < nchunk; ++i) {
         const int k = seq[i];
-        run_copies(cuts[k], cuts[k + 1], bp, &packed[k], &scope.all, small, [=](int j) {
+        run_copies(pool, cuts[k], cuts[k + 1], bp, &packed[k], &scope.all, small, [=](int j) {
             const long long L = lens[j];
             copy_stream(h_in + offs[j], in[ix[j]], (size_t)L * sizeof(short));
             const long long pad = align8(L) - L;
@@ -495,9 +557,11 @@ static int denoise_utterances_chunks(const short *const *in, short *const *out, 
     int next = 0, finished = 0;
     while (finished < nchunk) {
         bool progressed = false;
+        int r = 0;
         /* one upload at a time: concurrent uploads share the link, and the first kernel should start as early as it can */
         if (next < nchunk && packed[seq[next]].ready() &&
-            (next == 0 || hipEventQuery(w.ev_h2d[seq[next - 1]]) == hipSuccess)) {
+            (next == 0 || (r = evq(w.ev_h2d[seq[next - 1]], "hostpipe: upload event")) != 0)) {
+            if (r < 0) return 1; /* Scope waits for the pool and drains the streams */
             const int k = seq[next], i = next++;
             hipStream_t s = w.stream[i % kStreams];
             const int u0 = cuts[k], n = cuts[k + 1] - cuts[k];
@@ -528,7 +592,8 @@ static int denoise_utterances_chunks(const short *const *in, short *const *out, 
         }
         for (int i = 0; i < next; ++i) {
             const int k = seq[i];
-            if (state[k] == kComputing && hipEventQuery(w.ev_kernel[k]) == hipSuccess) {
+            if (state[k] == kComputing && (r = evq(w.ev_kernel[k], "hostpipe: kernel event")) != 0) {
+                if (r < 0) return 1; /* Scope waits for the pool and drains the streams */
                 hipStream_t s = w.stream[i % kStreams];
                 const long long o0 = pre[cuts[k]], cnt = pre[cuts[k + 1]] - o0;
                 if (!zc_out && !nocopy) HIP_TRY(hipMemcpyAsync(h_out + o0, w.out.d + o0, (size_t)cnt * sizeof(short), hipMemcpyDeviceToHost, s));
@@ -537,9 +602,10 @@ static int denoise_utterances_chunks(const short *const *in, short *const *out, 
                 state[k] = kDownloading;
                 progressed = true;
             }
-            if (state[k] == kDownloading && hipEventQuery(w.ev_done[k]) == hipSuccess) {
+            if (state[k] == kDownloading && (r = evq(w.ev_done[k], "hostpipe: download event")) != 0) {
+                if (r < 0) return 1; /* Scope waits for the pool and drains the streams */
                 if (trace) fprintf(stderr, "[hostpipe] %7.3f ms  chunk %d done on the device, unpacking\n", now_ms() - t0, k);
-                run_copies(cuts[k], cuts[k + 1], bp, &unpacked[k], &scope.all, small, [=](int j) {
+                run_copies(pool, cuts[k], cuts[k + 1], bp, &unpacked[k], &scope.all, small, [=](int j) {
                     /* the trailing partial frame stays untouched */
                     copy_stream(out[ix[j]], h_out + offs[j], (size_t)(lens[j] / 80 * 80) * sizeof(short));
                 });
@@ -606,9 +672,12 @@ static int denoise_utterances_slices(const short *const *in, short *const *out, 
     if (total_fr == 0) return 0;
     const long long max_fr = nfr[0];
     const long long total = total_fr * 80;
+    PipeWs &w = t_ws;
+    HIP_TRY(w.bind());
+    Pool &pool = Pool::get(w.device);
 
     /* slice boundaries in frames: equal shares of the samples */
-    const bool small = total * 2 < (2 << 20) || Pool::get().size() <= 1;
+    const bool small = total * 2 < (2 << 20) || pool.size() <= 1;
     int want = small ? 1 : (int)env_mb("SEA_HOST_SLICES", 8);
     want = (int)std::min<long long>(std::min(want, kMaxChunks), std::max<long long>(1, max_fr / 8));
     auto frames_below = [&](long long f) {
@@ -643,8 +712,6 @@ static int denoise_utterances_slices(const short *const *in, short *const *out, 
         soff[k + 1] = soff[k] + smp;
         mbase[k + 1] = mbase[k] + 2 * (size_t)n;
     }
-    PipeWs &w = t_ws;
-    HIP_TRY(w.bind());
     HIP_TRY(w.in.ensure((size_t)total));
     HIP_TRY(w.out.ensure((size_t)total));
     HIP_TRY(w.meta.ensure(mbase[K]));
@@ -670,7 +737,7 @@ static int denoise_utterances_slices(const short *const *in, short *const *out, 
     for (int k = 0; k < K; ++k) {
         const long long *offs = w.meta.h + mbase[k], *lens = offs + nact[k];
         const long long b0 = 80 * B[k];
-        run_copies(0, nact[k], bpre[k].data(), &packed[k], &scope.all, small,
+        run_copies(pool, 0, nact[k], bpre[k].data(), &packed[k], &scope.all, small,
                    [=](int j) { copy_stream(h_in + offs[j], in[ix[j]] + b0, (size_t)lens[j] * sizeof(short)); });
     }
     hipStream_t sUp = w.stream[0], sKern = w.stream[1], sDown = w.stream[2];
@@ -688,7 +755,9 @@ static int denoise_utterances_slices(const short *const *in, short *const *out, 
     int next = 0, finished = 0;
     while (finished < K) {
         bool progressed = false;
-        if (next < K && packed[next].ready() && (next == 0 || hipEventQuery(w.ev_h2d[next - 1]) == hipSuccess)) {
+        int r = 0;
+        if (next < K && packed[next].ready() && (next == 0 || (r = evq(w.ev_h2d[next - 1], "hostpipe: upload event")) != 0)) {
+            if (r < 0) return 1; /* Scope waits for the pool and drains the streams */
             const int k = next++;
             const long long cnt = soff[k + 1] - soff[k];
             if (trace) fprintf(stderr, "[hostpipe] %7.3f ms  slice %d packed (frames %lld..%lld of %d utterances, %.1f MB), issuing\n",
@@ -721,7 +790,8 @@ static int denoise_utterances_slices(const short *const *in, short *const *out, 
             progressed = true;
         }
         for (int k = 0; k < next; ++k) {
-            if (state[k] == kComputing && hipEventQuery(w.ev_kernel[k]) == hipSuccess) {
+            if (state[k] == kComputing && (r = evq(w.ev_kernel[k], "hostpipe: kernel event")) != 0) {
+                if (r < 0) return 1; /* Scope waits for the pool and drains the streams */
                 const long long cnt = soff[k + 1] - soff[k];
                 HIP_TRY(hipMemcpyAsync(h_out + soff[k], w.out.d + soff[k], (size_t)cnt * sizeof(short), hipMemcpyDeviceToHost, sDown));
                 HIP_TRY(hipEventRecord(w.ev_done[k], sDown));
@@ -729,11 +799,12 @@ static int denoise_utterances_slices(const short *const *in, short *const *out, 
                 progressed = true;
                 if (trace) fprintf(stderr, "[hostpipe] %7.3f ms  slice %d computed, downloading\n", now_ms() - t0, k);
             }
-            if (state[k] == kDownloading && hipEventQuery(w.ev_done[k]) == hipSuccess) {
+            if (state[k] == kDownloading && (r = evq(w.ev_done[k], "hostpipe: download event")) != 0) {
+                if (r < 0) return 1; /* Scope waits for the pool and drains the streams */
                 if (trace) fprintf(stderr, "[hostpipe] %7.3f ms  slice %d on the host, unpacking\n", now_ms() - t0, k);
                 const long long *offs = w.meta.h + mbase[k], *lens = offs + nact[k];
                 const long long b0 = 80 * B[k];
-                run_copies(0, nact[k], bpre[k].data(), &unpacked[k], &scope.all, small,
+                run_copies(pool, 0, nact[k], bpre[k].data(), &unpacked[k], &scope.all, small,
                            [=](int j) { copy_stream(out[ix[j]] + b0, h_out + offs[j], (size_t)lens[j] * sizeof(short)); });
                 state[k] = kUnpacking;
                 finished++;
@@ -777,7 +848,6 @@ int sea_denoise_ceps_utterances(const short *const *in, short *const *out, float
     HIP_TRY(w.out.ensure((size_t)total));
     HIP_TRY(w.meta.ensure(3 * (size_t)n_utt + 1));
     long long *offs = w.meta.h, *lens = w.meta.h + n_utt, *ccum = w.meta.h + 2 * n_utt;
-    std::vector<int> order(n_utt);
     for (int u = 0; u < n_utt; ++u) {
         offs[u] = pre[u];
         lens[u] = lengths[u];
@@ -786,33 +856,38 @@ int sea_denoise_ceps_utterances(const short *const *in, short *const *out, float
         if (pad) memset(w.in.h + pre[u] + lengths[u], 0, (size_t)pad * sizeof(short));
     }
     for (int u = 0; u <= n_utt; ++u) ccum[u] = cum[u];
-    launch_order(lens, n_utt, dc->n_cu, order.data());
-    DevBuf<float> d_f32, d_ceps;
-    DevBuf<int> d_first, d_nceps, d_order;
-    HIP_TRY(d_f32.alloc((size_t)total));
-    HIP_TRY(d_ceps.alloc((size_t)std::max<long long>(total_ceps, 1) * 14));
-    HIP_TRY(d_first.alloc(n_utt));
-    HIP_TRY(d_nceps.alloc(n_utt));
-    HIP_TRY(d_order.alloc(n_utt));
+    /* grow-only members of the workspace (round 3 allocated and freed five device buffers per call: an implicit device
+     * synchronisation for every other host thread of the process, and the file driver calls this per chunk) */
+    const size_t nceps_f = (size_t)std::max<long long>(total_ceps, 1) * 14;
+    HIP_TRY(w.f32.ensure((size_t)total));
+    HIP_TRY(w.ceps.ensure(nceps_f));
+    HIP_TRY(w.ints.ensure(3 * (size_t)n_utt));
+    int *d_first = w.ints.d, *d_nceps = w.ints.d + n_utt, *d_order = w.ints.d + 2 * n_utt;
+    int *h_nceps = w.ints.h + n_utt, *h_order = w.ints.h + 2 * n_utt;
+    launch_order(lens, n_utt, dc->n_cu, h_order);
     hipStream_t s = w.stream[0];
+    /* from the first asynchronous call on every exit path drains the stream (Scope: ok stays false on a fault), so no copy
+     * into w's pinned staging or kernel over w's device buffers is still in flight when the caller gets its fault code */
+    Scope scope(&w);
     HIP_TRY(hipMemcpyAsync(w.in.d, w.in.h, (size_t)total * sizeof(short), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(w.meta.d, w.meta.h, (3 * (size_t)n_utt + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_order.p, order.data(), (size_t)n_utt * sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemsetAsync(d_nceps.p, 0, (size_t)n_utt * sizeof(int), s));
-    if (sea_ns_denoise_batch(w.in.d, w.out.d, d_f32.p, w.meta.d, w.meta.d + n_utt, n_utt > 1 ? d_order.p : nullptr, d_first.p,
+    HIP_TRY(hipMemcpyAsync(d_order, h_order, (size_t)n_utt * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(d_nceps, 0, (size_t)n_utt * sizeof(int), s));
+    if (sea_ns_denoise_batch(w.in.d, w.out.d, w.f32.d, w.meta.d, w.meta.d + n_utt, n_utt > 1 ? d_order : nullptr, d_first,
                              n_utt, s))
         return 1;
-    if (total_ceps > 0 && sea_compceps_batch(d_f32.p, w.meta.d, w.meta.d + n_utt, d_first.p, w.meta.d + 2 * n_utt, total_ceps,
-                                             d_ceps.p, d_nceps.p, n_utt, s))
+    if (total_ceps > 0 && sea_compceps_batch(w.f32.d, w.meta.d, w.meta.d + n_utt, d_first, w.meta.d + 2 * n_utt, total_ceps,
+                                             w.ceps.d, d_nceps, n_utt, s))
         return 1;
-    std::vector<float> h_ceps((size_t)std::max<long long>(total_ceps, 1) * 14);
     HIP_TRY(hipMemcpyAsync(w.out.h, w.out.d, (size_t)total * sizeof(short), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(h_ceps.data(), d_ceps.p, h_ceps.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(n_ceps, d_nceps.p, (size_t)n_utt * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(w.ceps.h, w.ceps.d, nceps_f * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h_nceps, d_nceps, (size_t)n_utt * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    scope.ok = true;
     for (int u = 0; u < n_utt; ++u) {
+        n_ceps[u] = h_nceps[u];
         memcpy(out[u], w.out.h + pre[u], (size_t)(lengths[u] / 80 * 80) * sizeof(short));
-        if (n_ceps[u] > 0) memcpy(ceps[u], h_ceps.data() + (size_t)cum[u] * 14, (size_t)n_ceps[u] * 14 * sizeof(float));
+        if (n_ceps[u] > 0) memcpy(ceps[u], w.ceps.h + (size_t)cum[u] * 14, (size_t)n_ceps[u] * 14 * sizeof(float));
     }
     return 0;
 }
@@ -848,6 +923,7 @@ int sea_resynth_utterances(const short *const *in, const long *lengths, const fl
 
     PipeWs &w = t_ws;
     HIP_TRY(w.bind());
+    Pool &pool = Pool::get(w.device);
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     long long budget = (long long)((free_b + w.inter_bytes) / 10 * 6);
@@ -898,7 +974,7 @@ int sea_resynth_utterances(const short *const *in, const long *lengths, const fl
             lens[j] = lengths[idx[j]];
             moffs[j] = rpre[j] - rpre[cuts[k]];
         }
-    const bool small = (total * 4 + rows * 256) < (2 << 20) || n_utt == 1 || Pool::get().size() <= 1;
+    const bool small = (total * 4 + rows * 256) < (2 << 20) || n_utt == 1 || pool.size() <= 1;
 
     std::vector<Latch> packed(nchunk), unpacked(nchunk);
     Scope scope(&w);
@@ -909,7 +985,7 @@ int sea_resynth_utterances(const short *const *in, const long *lengths, const fl
     const long long *bp = bytes_pre.data(), *prep = pre.data(), *rprep = rpre.data();
     const int *ix = idx.data();
     for (int k = 0; k < nchunk; ++k)
-        run_copies(cuts[k], cuts[k + 1], bp, &packed[k], &scope.all, small, [=](int j) {
+        run_copies(pool, cuts[k], cuts[k + 1], bp, &packed[k], &scope.all, small, [=](int j) {
             const long long L = lens[j];
             copy_stream(h_in + prep[j], in[ix[j]], (size_t)L * sizeof(short));
             const long long pad = align8(L) - L;
@@ -925,6 +1001,7 @@ int sea_resynth_utterances(const short *const *in, const long *lengths, const fl
     int next = 0, finished = 0;
     while (finished < nchunk) {
         bool progressed = false;
+        int r = 0;
         /* a chunk reuses the scratch region and the stream of chunk k - nregion: stream order protects the region */
         if (next < nchunk && packed[next].ready()) {
             const int k = next++, r = k % nregion;
@@ -943,7 +1020,8 @@ int sea_resynth_utterances(const short *const *in, const long *lengths, const fl
             progressed = true;
         }
         for (int k = 0; k < next; ++k) {
-            if (state[k] == kComputing && hipEventQuery(w.ev_kernel[k]) == hipSuccess) {
+            if (state[k] == kComputing && (r = evq(w.ev_kernel[k], "hostpipe: kernel event")) != 0) {
+                if (r < 0) return 1; /* Scope waits for the pool and drains the streams */
                 const long long o0 = pre[cuts[k]], cnt = pre[cuts[k + 1]] - o0;
                 hipStream_t s = w.stream[k % nregion];
                 HIP_TRY(hipMemcpyAsync(h_out + o0, w.out.d + o0, (size_t)cnt * sizeof(short), hipMemcpyDeviceToHost, s));
@@ -951,8 +1029,9 @@ int sea_resynth_utterances(const short *const *in, const long *lengths, const fl
                 state[k] = kDownloading;
                 progressed = true;
             }
-            if (state[k] == kDownloading && hipEventQuery(w.ev_done[k]) == hipSuccess) {
-                run_copies(cuts[k], cuts[k + 1], bp, &unpacked[k], &scope.all, small,
+            if (state[k] == kDownloading && (r = evq(w.ev_done[k], "hostpipe: download event")) != 0) {
+                if (r < 0) return 1; /* Scope waits for the pool and drains the streams */
+                run_copies(pool, cuts[k], cuts[k + 1], bp, &unpacked[k], &scope.all, small,
                            [=](int j) { copy_stream(out[ix[j]], h_out + prep[j], (size_t)lens[j] * sizeof(short)); });
                 state[k] = kUnpacking;
                 finished++;

@@ -9,9 +9,10 @@
  * variant (160-sample frames, window 480, gammatone-shaped windows, rfft (x, 512, 8);
  * aurora_etsi/NoiseSup.cpp:1140-1407 -> csrc/ns16k_kernel.hip), including the line of 25 gains per second-stage frame
  * printed to the FILE* argument ("%f " each, then a newline; :1319-1328) when that is not NULL.
- * Extension: a non-NULL sm_glb_res is read as the DENOISEGlobalImpl the reference's commented-out line (:915) casts it
- * to ({int SamplingFrequency}, NoiseSupExports.h:9-12); SamplingFrequency == 8000 selects the etsi/ arithmetic instead
- * (80-sample frames, window 200, rfft 256, mel filter bank: the hot path's kernels; nothing is printed).
+ * sm_glb_res is ignored, as the reference ignores it (its cast to DENOISEGlobalImpl is commented out, :915, and
+ * SamplingFrequency forced to 16000).  Extension, opt-in through the environment only (SEA_MAPPING_8K=1 at global_init):
+ * the etsi/ arithmetic instead (80-sample frames, window 200, rfft 256, mel filter bank: the hot path's kernels; nothing
+ * is printed).
  * In both:
  *   - one call consumes dataNum / hop whole frames of inData and advances the per-thread state;
  *   - a frame whose float sum of squares truncates to 0 is skipped entirely (:1160-1171): no state change, its
@@ -140,7 +141,13 @@ int etsi_denoise_mapping_global_init(void **sm_glb_pins, void *sm_glb_res)
     if (sea_init(-1)) return 0;
     MapGlobal *g = new (std::nothrow) MapGlobal();
     if (!g) return 0;
-    g->sampling_frequency = (sm_glb_res && *(const int *)sm_glb_res == 8000) ? 8000 : 16000;
+    /* The reference ignores sm_glb_res entirely (the cast is commented out and SamplingFrequency forced to 16000,
+     * NoiseSup.cpp:913-922), so nothing is read through it here either: a caller passing a real DENOISEGlobalImpl -- or any
+     * other resource pointer -- gets the reference's behaviour.  The etsi/ arithmetic on 80-sample frames is an extension
+     * the reference cannot trigger: the environment variable SEA_MAPPING_8K=1, read once per global_init. */
+    (void)sm_glb_res;
+    const char *e8 = getenv("SEA_MAPPING_8K");
+    g->sampling_frequency = (e8 && e8[0] == '1') ? 8000 : 16000;
     if (hipGetDevice(&g->device) != hipSuccess) {
         delete g;
         return 0;

@@ -136,7 +136,10 @@ def test_etsi_denoise_mapping_symbols_16k_native(oracle, tmp_path):
     cut = 37
     want = [o.push(x[:160 * cut]), o.push(x[160 * cut:])]
     glb, thd = ctypes.c_void_p(), ctypes.c_void_p()
-    assert lib.etsi_denoise_mapping_global_init(ctypes.byref(glb), None) == 1
+    # a caller that passes a real DENOISEGlobalImpl {int SamplingFrequency} (NoiseSupExports.h:9-12) -- even one that says
+    # 8000 -- gets what the reference gives it: the argument is ignored (aurora_etsi/NoiseSup.cpp:913-922)
+    res = ctypes.c_int(8000)
+    assert lib.etsi_denoise_mapping_global_init(ctypes.byref(glb), ctypes.byref(res)) == 1
     assert lib.etsi_denoise_mapping_thread_init(ctypes.byref(thd), glb) == 1
     out = np.full(nfr * 160, -7.0, np.float32)
     arrs = [np.full(nfr, -7, np.int32) for _ in range(5)]

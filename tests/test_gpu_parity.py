@@ -329,6 +329,63 @@ def test_denoise_utterances_pipeline_any_chunking(oracle, monkeypatch):
         check(f"chunks of {mb} MB")
 
 
+def test_host_pipeline_returns_fault_on_event_error(oracle, monkeypatch):
+    """The three event-driven pipelines of csrc/hostpipe.hip poll hipEventQuery; any answer other than "done" / "not
+    ready" must end the call with the reference's fault code 1 (etsi/cpp/AdvFrontEnd.c:205-209) -- not be polled for
+    ever -- with the pool idle and the streams drained, and the next call must work.  sea_selftest_hostpipe_fault makes
+    the nth query of the process report a device fault."""
+    import ctypes
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    _torch()
+    lib = sea.load()
+    lens = [24000 + 160 * i for i in range(48)]            # 2.3 MB of int16: the pipeline, not the inline path
+    utts = [corpus.synth_utterance(900 + i, L) for i, L in enumerate(lens)]
+    masks = [corpus.synth_mask(900 + i, L) for i, L in enumerate(lens)]
+    n = len(utts)
+    pin = (ctypes.c_void_p * n)(*[x.ctypes.data for x in utts])
+    pl = (ctypes.c_long * n)(*lens)
+    pm = (ctypes.c_void_p * n)(*[m.ctypes.data for m in masks])
+
+    def denoise():
+        outs = [np.zeros_like(x) for x in utts]
+        po = (ctypes.c_void_p * n)(*[y.ctypes.data for y in outs])
+        return lib.sea_denoise_utterances(pin, po, pl, n), outs
+
+    def resynth():
+        outs = [np.zeros_like(x) for x in utts]
+        po = (ctypes.c_void_p * n)(*[y.ctypes.data for y in outs])
+        return lib.sea_resynth_utterances(pin, pl, pm, 0, po, n), outs
+
+    rc, good = denoise()
+    assert rc == 0, lib.sea_last_error()
+    rc, good_rs = resynth()
+    assert rc == 0, lib.sea_last_error()
+    try:
+        for mode in (None, "chunks"):
+            if mode:
+                monkeypatch.setenv("SEA_HOST_MODE", mode)
+            for nth in (1, 3, 9):
+                lib.sea_selftest_hostpipe_fault(nth)
+                rc, _ = denoise()
+                assert rc == 1, f"{mode or 'slices'}: fault at query {nth} was not reported"
+                assert b"event" in lib.sea_last_error()
+                lib.sea_selftest_hostpipe_fault(0)
+                rc, outs = denoise()
+                assert rc == 0, lib.sea_last_error()
+                assert all(np.array_equal(a, b) for a, b in zip(outs, good)), "the call after a fault differs"
+        monkeypatch.delenv("SEA_HOST_MODE", raising=False)
+        lib.sea_selftest_hostpipe_fault(2)
+        rc, _ = resynth()
+        assert rc == 1
+        lib.sea_selftest_hostpipe_fault(0)
+        rc, outs = resynth()
+        assert rc == 0, lib.sea_last_error()
+        assert all(np.array_equal(a, b) for a, b in zip(outs, good_rs))
+    finally:
+        lib.sea_selftest_hostpipe_fault(0)
+
+
 def test_gammatone_filter_vs_oracle(oracle):
     import speech_enhancement_amd as sea
     _torch()
@@ -791,10 +848,11 @@ def test_ns_stream_plugin_flags_vs_oracle(oracle):
         assert np.array_equal(out[b, 4:].reshape(-1).view(np.uint32), ns["den_f32"].view(np.uint32))
 
 
-def test_etsi_denoise_mapping_symbols(oracle):
+def test_etsi_denoise_mapping_symbols(oracle, monkeypatch):
     """The reference's batch plug-in symbols (function/20141106_speech_enhancement/aurora_etsi/NoiseSupExports.h:35-42)
-    in their 8 kHz-mode (etsi/ arithmetic) extension -- sm_glb_res -> {SamplingFrequency 8000}; the default, the 16 k-native
-    variant, is tests/test_gpu_ns16k.py -- through the C ABI: global / thread instances, two
+    in their 8 kHz-mode (etsi/ arithmetic) extension -- opt-in through SEA_MAPPING_8K=1 only: sm_glb_res is ignored as the
+    reference ignores it (aurora_etsi/NoiseSup.cpp:913-922); the default, the 16 k-native variant, is
+    tests/test_gpu_ns16k.py -- through the C ABI: global / thread instances, two
     func_Wiener calls on one thread instance (the state crosses the calls), zero frames skipped without touching
     their output entries (aurora_etsi/NoiseSup.cpp:1160-1171), a second thread instance starting afresh."""
     import ctypes
@@ -818,8 +876,9 @@ def test_etsi_denoise_mapping_symbols(oracle):
     keep = np.array([n for n in range(nfr) if np.any(x[80 * n:80 * n + 80])])
     assert len(keep) == nfr - 5 - 3
     glb, thd = ctypes.c_void_p(), ctypes.c_void_p()
-    res = ctypes.c_int(8000)                          # DENOISEGlobalImpl {int SamplingFrequency}, NoiseSupExports.h:9-12
-    assert lib.etsi_denoise_mapping_global_init(ctypes.byref(glb), ctypes.byref(res)) == 1
+    monkeypatch.setenv("SEA_MAPPING_8K", "1")         # read by global_init
+    assert lib.etsi_denoise_mapping_global_init(ctypes.byref(glb), None) == 1
+    monkeypatch.delenv("SEA_MAPPING_8K")
     for attempt in range(2):                          # the second pass: a fresh thread instance gives the same again
         assert lib.etsi_denoise_mapping_thread_init(ctypes.byref(thd), glb) == 1
         xf = x.astype(np.float32)
