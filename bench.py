@@ -71,9 +71,13 @@ def parse_args(argv=None):
     ap.add_argument("--no-also", action="store_true", help="skip the resynth / CompCeps / rfft256 lines")
     ap.add_argument("--also-steps", type=int, default=5)
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the PCIe-inclusive host-buffer timings")
-    ap.add_argument("--no-configs4", action="store_true", help="skip the configs[4] shard line of the also-array")
+    ap.add_argument("--no-configs4", action="store_true",
+                    help="skip the configs[4] lines (the one-shard line of the also-array and the whole-corpus `configs4` object)")
+    ap.add_argument("--configs4-utts", type=int, default=100000,
+                    help="size of the corpus of the `configs4` object (BASELINE configs[4]: 100000), cut into one LPT shard per rank")
     ap.add_argument("--cpu-utts", type=int, default=1024, help="utterances in the bounded CPU sample (1024 = ~10 core-seconds)")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the CPU baseline (the 1-GPU box share is 16)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="host threads for the CPU baseline (default 0 = every CPU this process may run on; 16 is reported beside)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="no GPU work: launcher, gloo rendezvous, shard assignment and the job reduction only (CPU tests)")
     return ap.parse_args(argv)
@@ -257,21 +261,50 @@ def init_gloo(rank, world):
         dist.barrier()
 
 
-def _time_cpu(fn, utts, cores, passes):
-    from concurrent.futures import ThreadPoolExecutor
-    outs = [None] * len(utts)
-
-    def work(i):
-        outs[i] = fn(utts[i])
-
-    fn(utts[0][:800])  # one-time table init outside the timed region
+def _time_cpu(lib, symbol, utts, threads, seconds=2.0):
+    """Frames per second of `symbol` (an etsi_denoise-shaped C function of the ctypes library `lib`) over `utts` on
+    `threads` host threads: oracle/cpu_pool.c's workers pull utterances from a shared counter (the reference harness's own
+    shape, aurora_speech_enhancement.cpp:111-121), so a many-core host is not paced by a Python dispatcher.  One pass to
+    warm up (tables, page faults), two for an estimate, then as many as fill about `seconds`.  Returns (frames/s, passes, outs)."""
+    import ctypes
+    pool = ctypes.CDLL(os.path.join(ROOT, "oracle", "libsea_cpupool.so"))
+    pool.sea_cpu_pool_run.restype = ctypes.c_double
+    pool.sea_cpu_pool_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long,
+                                      ctypes.c_int, ctypes.c_int]
+    fn = ctypes.cast(getattr(lib, symbol), ctypes.c_void_p)
+    n = len(utts)
+    outs = [np.zeros_like(u) for u in utts]
+    pin = (ctypes.c_void_p * n)(*[u.ctypes.data for u in utts])
+    pout = (ctypes.c_void_p * n)(*[o.ctypes.data for o in outs])
+    lens = (ctypes.c_long * n)(*[u.size for u in utts])
+    frames = int(sum(u.size // 80 for u in utts))
     with quiet_stderr():
-        with ThreadPoolExecutor(max_workers=cores) as ex:
-            t0 = time.perf_counter()
-            for _ in range(passes):
-                list(ex.map(work, range(len(utts))))
-            dt = time.perf_counter() - t0
-    return dt, outs
+        pool.sea_cpu_pool_run(fn, pin, pout, lens, n, threads, 1)       # tables, page faults
+        dt = pool.sea_cpu_pool_run(fn, pin, pout, lens, n, threads, 2)  # an estimate
+        if dt <= 0:
+            raise RuntimeError("cpu pool: thread creation failed")
+        passes = int(min(64, max(2, seconds / (dt / 2))))
+        dt = pool.sea_cpu_pool_run(fn, pin, pout, lens, n, threads, passes)
+    return passes * frames / dt, passes, outs
+
+
+def cpu_quota():
+    """The CPU time this process may use per second as the cgroup says it (cpu.max), or None: a box can show 256 CPUs
+    in the affinity mask and still be held to a share of them."""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                t = f.read().split()
+            if path.endswith("cpu.max"):
+                return None if t[0] == "max" else float(t[0]) / float(t[1])
+            q = float(t[0])
+            if q <= 0:
+                return None
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                return q / float(f.read())
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
 
 
 def cpu_model():
@@ -292,47 +325,60 @@ def cpu_model():
 
 
 def cpu_baseline(batch, n_sample, threads):
-    """kind "port": the oracle's C restatement, one utterance per thread over the host cores, on the
-    first n_sample utterances of the shard.  Two builds, as BASELINE.md section 3 promised: the parity
-    build (-O2, no FMA contraction: oracle/libsea_oracle.so) and a speed build compiled HERE for this
-    host (-O3 -march=native); `value` is the faster.  Where oracle/_ref (the reference C compiled from
-    its own sources) shipped with the tree it is timed too and reported beside as `reference_value`."""
+    """kind "port": the oracle's C restatement, one utterance per thread over ALL the host cores this process may run
+    on (len(os.sched_getaffinity(0)); --cpu-threads overrides), on the first n_sample utterances of the shard; the
+    16-thread figure of rounds 1-3 is kept beside it.  Two builds, as BASELINE.md section 3 promised: the parity build
+    (-O2, no FMA contraction: oracle/libsea_oracle.so) and a speed build compiled HERE for this host (-O3
+    -march=native); `value` is the faster.  Where oracle/_ref (the reference C compiled from its own sources) shipped
+    with the tree it is timed the same way and reported beside as `reference_value` (etsi/cpp/AdvFrontEnd.c:125-210
+    per thread)."""
+    import ctypes
     from oracle import oracle as O
     host = batch.data.cpu().numpy()
     n_sample = min(n_sample, batch.n_utt)
     utts = [np.ascontiguousarray(host[o:o + l]) for o, l in
             zip(batch.host_offsets[:n_sample], batch.host_lengths[:n_sample])]
-    frames = int(sum(len(u) // 80 for u in utts))
-    cores = max(1, min(threads, len(os.sched_getaffinity(0))))
-    passes = 2
+    usable = len(os.sched_getaffinity(0))
+    cores = max(1, min(threads, usable)) if threads > 0 else usable
+    side = 16 if cores > 16 else 0   # the figure of rounds 1-3, beside
     parity = O.Oracle()
-    dt_par, outs = _time_cpu(parity.etsi_denoise, utts, cores, passes)
-    res = dict(unit="frames/s", cores=cores, kind="port", parity_build_value=passes * frames / dt_par,
+    v, passes, outs = _time_cpu(parity.lib, "ora_etsi_denoise", utts, cores)
+    res = dict(unit="frames/s", cores=cores, kind="port", parity_build_value=v,
                parity_build="gcc -O2 -ffp-contract=off (oracle/libsea_oracle.so)")
     res["cpu_model"] = cpu_model()
-    best = res["parity_build_value"]
+    quota = cpu_quota()
+    res["cgroup_cpu_quota"] = quota if quota is not None else "none (cpu.max = max)"
+    if side:
+        res["threads16"] = {"parity_build_value": _time_cpu(parity.lib, "ora_etsi_denoise", utts, side)[0]}
+    best = v
     tmp = tempfile.mkdtemp(prefix="sea_cpu_")
     try:  # the speed build must be made on the box it runs on (-march=native)
         so = os.path.join(tmp, "libsea_oracle_native.so")
         subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-o", so,
                                os.path.join(ROOT, "oracle", "ns_oracle.c"), os.path.join(ROOT, "oracle", "resynth_oracle.c"),
                                "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        speed = O.Oracle(path=so)
-        dt_spd, _ = _time_cpu(speed.etsi_denoise, utts, cores, passes)
-        res["speed_build_value"] = passes * frames / dt_spd
+        speed = ctypes.CDLL(so)
+        res["speed_build_value"] = _time_cpu(speed, "ora_etsi_denoise", utts, cores)[0]
         res["speed_build"] = "gcc -O3 -march=native (FMA allowed: not bit-exact, timing only)"
+        if side:
+            res["threads16"]["speed_build_value"] = _time_cpu(speed, "ora_etsi_denoise", utts, side)[0]
         best = max(best, res["speed_build_value"])
     except Exception as e:  # no compiler on the box: say so, keep the parity build
         res["speed_build"] = f"unavailable ({type(e).__name__})"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)  # a loaded mapping stays valid after the file is gone
     if O.have_reference():
-        dt_ref, _ = _time_cpu(O.Reference().etsi_denoise, utts, cores, passes)
-        res["reference_value"] = passes * frames / dt_ref
+        ref = O.Reference()
+        res["reference_value"] = _time_cpu(ref.lib, "ref_etsi_denoise", utts, cores)[0]
         res["reference_build"] = "the reference's etsi/cpp/*.c, gcc -O2 -ffp-contract=off (oracle/_ref)"
+        if side:
+            res["threads16"]["reference_value"] = _time_cpu(ref.lib, "ref_etsi_denoise", utts, side)[0]
     res["value"] = best
-    res["sample"] = (f"{passes} passes over the first {len(utts)} utterances of the shard per build "
-                     f"({passes * frames} frames each) on {cores} threads; value = the faster of the port's two builds")
+    frames = int(sum(len(u) // 80 for u in utts))
+    res["sample"] = (f"the first {len(utts)} utterances of the shard ({frames} frames per pass), {passes}+ passes per build "
+                     f"(2 to warm up, then ~2 s worth) on {cores} threads = every CPU this process may run on, utterances "
+                     "pulled from a shared counter (oracle/cpu_pool.c); value = the faster of the port's two builds; "
+                     "threads16 = the same on 16 threads (the figure of rounds 1-3)")
     return res, outs
 
 
@@ -552,15 +598,64 @@ def configs4_line(device, steps):
             o, l = int(batch.host_offsets[u]), int(batch.host_lengths[u])
             want = ora.etsi_denoise(np.ascontiguousarray(host_in[o:o + l]))
             bad += int(not np.array_equal(host_out[o:o + l // 80 * 80], want[:l // 80 * 80]))
+    traffic, tnote = pmc_traffic("ns_big_bytes_per_launch")
+    insts, _ = pmc_traffic("ns_big_valu_insts_per_launch")
+    clk, _ = pmc_traffic("ns_big_valu_issue_clk_per_launch")
     d = {"name": "NoiseSup, configs[4] shard", "workload": f"BASELINE configs[4]: shard 0 of 8 (LPT by samples) of the 100000-utterance "
          f"corpus = {batch.n_utt} utterances, {frames} frames, one launch", "value": frames / wall, "unit": "frames/s",
          "ms_per_step": wall * 1e3, "steps": steps, "rtf": wall / (frames * 80 / 16000.0),
          "parity_check": f"{len(pick) - bad}/{len(pick)} sampled utterances bit-identical to the CPU oracle",
          "roofline": {"bound": "hbm", "kernel": "sea::ns_denoise_pipe_big_kernel", "achieved": alg / ker / 1e9, "peak": HBM_PEAK_GBPS,
-                      "unit": "GB/s", "frac": alg / ker / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                      "unit": "GB/s", "frac": alg / ker / 1e9 / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tnote,
+                      "traffic_over_algorithmic": (traffic / alg) if traffic else None,
                       "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ker * 1e3}}
+    if insts:  # the big form's own counter passes (tools/profile_round.sh, same shard)
+        d["roofline"]["valu_insts_per_frame"] = insts / frames
+        if clk:
+            d["roofline"]["valu_issue_ms"] = clk / (1024 * 2.4e9) * 1e3
+            d["roofline"]["valu_issue_frac"] = clk / (1024 * 2.4e9) / ker
     del batch, out
     return d, bad
+
+
+def configs4_whole(world, rank, device, dist, steps, corpus_utts=100000):
+    """BASELINE configs[4] as BASELINE.json defines it for N GPUs: the WHOLE 100 000-utterance corpus over the N ranks of
+    this job -- cut into N shards balanced by samples (LPT), rank r holds shard r in HBM and runs it as one launch per
+    step, no collective on the data path -- so that the driver's N = 1, 2, 4, 8 runs of this script are a STRONG-scaling
+    curve of one fixed corpus (the reference's shape: the shared-counter pool over files,
+    aurora_speech_enhancement.cpp:311-327).  Barrier + synchronize on both sides; value = all frames / max over ranks."""
+    import torch
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd.shard import reduce_job
+    ids = corpus_shard_ids(corpus_utts, world, rank)
+    batch = build_shard_ids(ids, device)
+    out = torch.zeros_like(batch.data)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    sea.ns_denoise_batch(batch, out=out)   # warm-up
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sea.ns_denoise_batch(batch, out=out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    total, dt_max = reduce_job(batch.n_frames * steps, dt, dist if world > 1 else None)
+    # size-independent property on every utterance of the shard (SURVEY F7): nothing before frame 4 of the first
+    # non-silent frame; checked exactly against the oracle at N = 1 by configs4_line / the full-size tests
+    d = {"name": "NoiseSup, configs[4] whole corpus", "value": total / dt_max, "unit": "frames/s", "n_gpus": world,
+         "scaling": "strong", "steps": steps, "ms_per_step": dt_max / steps * 1e3,
+         "rtf": dt_max / (total * 80 / 16000.0),
+         "workload": f"BASELINE configs[4]: the whole {corpus_utts}-utterance synthetic corpus ({total // steps} frames) cut into "
+                     f"{world} LPT shard(s), one per GPU, {batch.n_utt} utterances on rank 0, one launch per step and GPU",
+         "frac_hbm": total / dt_max * NS_BYTES_PER_FRAME / 1e9 / (HBM_PEAK_GBPS * world)}
+    del batch, out
+    return d
 
 
 def cli_wall_clock(ins):
@@ -672,9 +767,19 @@ def rehearse_cpu(args, world, rank):
     if world > 1:
         dist.barrier()
     total, tmax = reduce_job(frames * args.steps, 1.0 + rank, dist if world > 1 else None)
+    c4 = None
+    if args.corpus_utts == 0 and not args.no_configs4:   # the `configs4` object: the whole corpus over the ranks of the job
+        ids4 = corpus_shard_ids(args.configs4_utts, world, rank)
+        fr4 = int(sum(corpus.utterance_length(int(u)) // 80 for u in ids4))
+        if world > 1:
+            dist.barrier()
+        tot4, t4 = reduce_job(fr4 * 2, 2.0 + rank, dist if world > 1 else None)
+        c4 = {"n_gpus": world, "scaling": "strong", "total_frames": tot4, "seconds_max": t4, "utterances_rank0": len(ids4),
+              "frames_rank0": fr4}
     if rank == 0:
         print(json.dumps({"rehearsal": True, "n_gpus": world, "steps": args.steps, "total_frames": total,
-                          "seconds_max": tmax, "utterances_rank0": len(ids), "first_ids_rank0": [int(u) for u in ids[:4]]}),
+                          "seconds_max": tmax, "utterances_rank0": len(ids), "first_ids_rank0": [int(u) for u in ids[:4]],
+                          "configs4": c4}),
               flush=True)
     if world > 1:
         dist.barrier()
@@ -825,6 +930,13 @@ def run_rank(args):
                 result["also"].insert(0, c4)
                 if bad4:
                     rc = 3
+    if args.corpus_utts == 0 and not args.no_configs4 and not args.no_also:
+        # every rank takes part (N > 1: the also-array of the other kernels is an N = 1 matter, this line is not)
+        batch = out = None   # this rank's configs[1] shard leaves the HBM
+        torch.cuda.empty_cache()
+        c4w = configs4_whole(world, rank, device, dist if world > 1 else None, 2, args.configs4_utts)
+        if rank == 0:
+            result["configs4"] = c4w
     if world > 1:
         dist.barrier()
     if rank == 0:

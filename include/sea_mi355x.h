@@ -50,8 +50,11 @@ int etsi_denoise_16k(short *p_data, short *p_denoised, long i_frame);
 /* etsi/cpp/AdvFrontEnd.h:17 -- AdvFrontEnd.c:316-329 calls the 8 kHz-mode etsi_denoise (not the _16k one): the same
  * behaviour as etsi_denoise_synchronization, returns 0 and never writes p_denoised on success. */
 int etsi_denoise_16k_synchronization(short *p_data, short *p_denoised, long i_frame);
-/* etsi/cpp/rfft.h:19 -- in-place real split-radix FFT, output Re(0..n/2), Im(n/2-1..1).
- * Only n = 256, m = 8 (the one size on the hot path) is implemented; other sizes abort(). */
+/* etsi/cpp/rfft.h:19 -- in-place real split-radix FFT, output Re(0..n/2), Im(n/2-1..1), for every size the
+ * reference's routine takes (etsi/cpp/rfft.c:45-180): n a power of two (here up to 16384) and any order m with
+ * 2^m <= n -- incl. the 16 k-native variant's rfft (x, 512, 8), order 8 on length 512.  A size the routine cannot
+ * take (or a missing device) leaves x untouched, prints the reason to stderr and sets sea_last_error(); nothing
+ * abort()s the caller. */
 void rfft(float *x, int n, int m);
 
 /* ----------------------------------------------------------------------------------------------
@@ -82,6 +85,9 @@ int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
                          int *d_first_out, int n_utt, void *stream);
 /* rfft on [nframes][256] floats (d_out may equal d_in) */
 int sea_rfft256_batch(const float *d_in, float *d_out, long long nframes, void *stream);
+/* rfft (x, n, m) in place on [nframes][n] floats, any size the reference's routine takes (see rfft above); (256, 8)
+ * goes to the streaming kernel, every other size to a one-workgroup-per-frame schedule walker */
+int sea_rfft_batch(float *d_x, int n, int m, long long nframes, void *stream);
 /* DoCompCeps on [nframes][201] floats (Data[-1..199]) -> [nframes][14] = c1..c12, c0, logE */
 int sea_compceps_frames(const float *d_data201, float *d_coef14, long long nframes, void *stream);
 /* CompCeps straight from the float NoiseSup stream of sea_ns_denoise_batch.  d_ceps_cum holds

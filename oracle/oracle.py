@@ -54,11 +54,13 @@ class _Lib:
         self._f("etsi_denoise")(_ptr(x), _ptr(out), ctypes.c_long(x.size))
         return out
 
-    def rfft(self, x):
+    def rfft(self, x, m=None):
+        """rfft (x, n, m), etsi/cpp/rfft.c:45-180; m defaults to log2 n (any 2^m <= n is accepted, as by the reference)"""
         y = np.array(x, dtype=np.float32, copy=True)
         n = y.size
-        m = int(np.log2(n))
-        assert 1 << m == n
+        if m is None:
+            m = int(np.log2(n))
+        assert 1 << int(np.log2(n)) == n and (1 << m) <= n
         self._f("rfft")(_ptr(y), ctypes.c_int(n), ctypes.c_int(m))
         return y
 

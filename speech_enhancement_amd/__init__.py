@@ -15,5 +15,5 @@ from . import corpus  # noqa: F401
 from ._lib import LIB_PATH, SeaError, load  # noqa: F401
 from .engine import (DoCompCeps, MaskBatch, NoiseSup, PackedBatch, afe_features_batch, compceps_batch,  # noqa: F401
                      compceps_frames, etsi_denoise, gammaToneFilter, irm_target, irm_target_batch, ns_denoise_batch,
-                     ns16k_streams_push, ns16k_tables, ns_streams_push, resynth, resynth_batch, resynth_scratch_elems, rfft, rfft_batch, subband_batch, subbband,
+                     ns16k_streams_push, ns16k_tables, ns_streams_push, resynth, resynth_batch, resynth_scratch_elems, rfft, rfft_any_batch, rfft_batch, subband_batch, subbband,
                      tables)

@@ -29,6 +29,7 @@ PROTOTYPES = {
     "sea_gammatone_channels": (_i, [_vp, _vp, _vp]),
     "sea_ns_denoise_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sea_rfft256_batch": (_i, [_vp, _vp, _ll, _vp]),
+    "sea_rfft_batch": (_i, [_vp, _i, _i, _ll, _vp]),
     "sea_compceps_frames": (_i, [_vp, _vp, _ll, _vp]),
     "sea_compceps_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp, _i, _vp]),
     "sea_ns_kernel_form": (_i, [_i]),

@@ -402,20 +402,63 @@ int etsi_denoise_16k_synchronization(short *p_data, short *p_denoised, long i_fr
     return etsi_denoise_synchronization(p_data, p_denoised, i_frame);
 }
 
+/* nframes transforms rfft (x, n, m) in place on device memory: [nframes][n] floats.  (256, 8) -- the hot path's size --
+ * runs the streaming kernel; every other size the reference's routine takes (n = 2^q <= 16384, 2^m <= n;
+ * etsi/cpp/rfft.c:45-180) the one-workgroup schedule walker.  The schedule of a size is built once per device. */
+int sea_rfft_batch(float *d_x, int n, int m, long long nframes, void *stream)
+{
+    if (nframes <= 0) return 0;
+    if (n == 256 && m == 8) return sea_rfft256_batch(d_x, d_x, nframes, stream);
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    struct Sched {
+        int device, n, m;
+        unsigned *d;
+    };
+    static std::mutex mu;
+    static std::vector<Sched> cache;
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    unsigned *d_sched = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Sched &e : cache)
+            if (e.device == dev && e.n == n && e.m == m) d_sched = e.d;
+        if (!d_sched) {
+            unsigned long words = 0;
+            unsigned *h = sea_rfft_schedule(n, m, &words);
+            if (!h) return fail("rfft: size n=%d, m=%d is outside what etsi/cpp/rfft.c:45-180 can take here (n a power of two <= %d, 2^m <= n)", n, m, (int)SEA_RFFT_MAXN);
+            hipError_t e = hipMalloc((void **)&d_sched, words * sizeof(unsigned));
+            if (e == hipSuccess) e = hipMemcpy(d_sched, h, words * sizeof(unsigned), hipMemcpyHostToDevice);
+            free(h);
+            if (e != hipSuccess) {
+                if (d_sched) (void)hipFree(d_sched);
+                return fail("rfft: schedule upload: %s", hipGetErrorString(e));
+            }
+            cache.push_back(Sched{dev, n, m, d_sched});
+        }
+    }
+    const long long grid = nframes < 8LL * c->n_cu ? nframes : 8LL * c->n_cu;
+    hipLaunchKernelGGL(sea::rfft_any_kernel, dim3((unsigned)grid), dim3(256), (size_t)n * sizeof(float), (hipStream_t)stream, d_x,
+                       d_sched, nframes);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* etsi/cpp/rfft.h:19.  The reference's routine returns nothing and cannot fail; here a size it could not take either
+ * (n not a power of two: its digit-reverse counter does not terminate properly; 2^m > n: it indexes past x) or that does
+ * not fit this engine (n > 16384), or a missing device, leaves x UNTOUCHED, prints the reason to stderr and sets
+ * sea_last_error() -- it no longer abort()s the caller's process. */
 void rfft(float *x, int n, int m)
 {
-    if (n != 256 || m != 8) {
-        fprintf(stderr, "ERROR:   rfft (MI355X): only n=256, m=8 is implemented (got n=%d, m=%d)\r\n", n, m);
-        abort();
-    }
+    if (!x || n < 2) return;
     DevBuf<float> d;
-    bool ok = d.alloc(256) == hipSuccess && hipMemcpy(d.p, x, 256 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
-              sea_rfft256_batch(d.p, d.p, 1, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess &&
-              hipMemcpy(x, d.p, 256 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
-    if (!ok) {
-        fprintf(stderr, "ERROR:   rfft (MI355X): no usable gfx950 device: %s\r\n", last_error());
-        abort();
-    }
+    const size_t bytes = (size_t)n * sizeof(float);
+    bool ok = d.alloc((size_t)n) == hipSuccess && hipMemcpy(d.p, x, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) ok = sea_rfft_batch(d.p, n, m, 1, nullptr) == 0;
+    else fail("rfft: no usable gfx950 device or allocation failure");
+    if (ok) ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(x, d.p, bytes, hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) fprintf(stderr, "ERROR:   rfft (MI355X): n=%d, m=%d not transformed: %s\r\n", n, m, last_error());
 }
 
 int sea_compceps_frame(const float *Data, float *Coef14)

@@ -85,6 +85,87 @@ __global__ __launch_bounds__(64, SEA_RFFT_WAVES) void rfft256_kernel(const float
     }
 }
 
+/* rfft (x, n, m) for every size the reference's routine takes (etsi/cpp/rfft.c:45-180): ONE workgroup per transform walks
+ * the schedule sea_rfft_schedule() unrolled on the host -- digit reversal, the length-two butterflies, then level by
+ * level the plain, pi/4 and twiddled butterflies of all blocks, which touch disjoint elements within a level -- with the
+ * frame in LDS (n floats, dynamic).  A convenience path behind the drop-in symbol (the hot path's only size, (256, 8),
+ * keeps rfft256_kernel; the 16 k-native variant's (512, 8) keeps its own register schedule in ns16k_kernel.hip): written
+ * for exactness -- the reference's operations in the reference's order per butterfly -- not for speed. */
+__global__ __launch_bounds__(256) void rfft_any_kernel(float *x, const unsigned *sched, long long nframes)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int n = (int)sched[0], m = (int)sched[1];
+    const unsigned *rev = sched + sched[2], *len2 = sched + sched[3];
+    const int nlen2 = (int)sched[4], tid = threadIdx.x;
+    for (long long f = blockIdx.x; f < nframes; f += gridDim.x) {
+        float *xf = x + f * n;
+        for (int i = tid; i < n; i += 256) xs[rev[i]] = xf[i];
+        __syncthreads();
+        for (int w = tid; w < nlen2; w += 256) { /* :82-96 */
+            const int i0 = (int)len2[w];
+            const float a0 = xs[i0], a1 = xs[i0 + 1];
+            xs[i0] = a0 + a1;
+            xs[i0 + 1] = a0 - a1;
+        }
+        __syncthreads();
+        int n2 = 2;
+        for (int k = 1; k < m; ++k) {
+            n2 <<= 1;
+            const int n4 = n2 >> 2, n8 = n2 >> 3, per = n8 > 0 ? n8 : 1;
+            const unsigned *blk = sched + sched[5 + 3 * k];
+            const float *tw = reinterpret_cast<const float *>(sched + sched[7 + 3 * k]);
+            const int items = (int)sched[6 + 3 * k] * per;
+            for (int w = tid; w < items; w += 256) {
+                const int i = (int)blk[w / per], j = w % per;
+                if (j == 0) {
+                    { /* :108-115 */
+                        const int i1 = i, i3 = i1 + 2 * n4, i4 = i3 + n4;
+                        const float x1 = xs[i1], x3 = xs[i3], x4 = xs[i4];
+                        const float t1 = x4 + x3;
+                        xs[i4] = x4 - x3;
+                        xs[i3] = x1 - t1;
+                        xs[i1] = x1 + t1;
+                    }
+                    if (n4 != 1) { /* :117-128; the division by sqrt 2 in double == this multiplication for every float
+                                      (sea_device.h, swept over all 2^32 by sea_selftest_pi4) */
+                        const int i1 = i + n8, i2 = i1 + n4, i3 = i2 + n4, i4 = i3 + n4;
+                        const float x1 = xs[i1], x2 = xs[i2], x3 = xs[i3], x4 = xs[i4];
+                        const float t1 = (float)((double)(x3 + x4) * 0.70710678118654752440);
+                        const float t2 = (float)((double)(x3 - x4) * 0.70710678118654752440);
+                        xs[i4] = x2 - t1;
+                        xs[i3] = -x2 - t1;
+                        xs[i2] = x1 - t2;
+                        xs[i1] = x1 + t2;
+                    }
+                } else { /* :145-174 */
+                    const float cc1 = tw[4 * j], ss1 = tw[4 * j + 1], cc3 = tw[4 * j + 2], ss3 = tw[4 * j + 3];
+                    const int i1 = i + j, i2 = i1 + n4, i3 = i2 + n4, i4 = i3 + n4;
+                    const int i5 = i + n4 - j, i6 = i5 + n4, i7 = i6 + n4, i8 = i7 + n4;
+                    const float x1 = xs[i1], x2 = xs[i2], x3 = xs[i3], x4 = xs[i4], x5 = xs[i5], x6 = xs[i6], x7 = xs[i7], x8 = xs[i8];
+                    float t1 = x3 * cc1 + x7 * ss1;
+                    float t2 = x7 * cc1 - x3 * ss1;
+                    float t3 = x4 * cc3 + x8 * ss3;
+                    float t4 = x8 * cc3 - x4 * ss3;
+                    const float t5 = t1 + t3, t6 = t2 + t4;
+                    t3 = t1 - t3;
+                    t4 = t2 - t4;
+                    xs[i3] = t6 - x6;
+                    xs[i8] = x6 + t6;
+                    xs[i7] = -x2 - t3;
+                    xs[i4] = x2 - t3;
+                    xs[i6] = x1 - t5;
+                    xs[i1] = x1 + t5;
+                    xs[i5] = x5 - t4;
+                    xs[i2] = x5 + t4;
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < n; i += 256) xf[i] = xs[i];
+        __syncthreads();
+    }
+}
+
 /* ==================================================================================================
  * Tiled CompCeps: one wave owns a TILE of kCcT consecutive frames.
  *

@@ -161,6 +161,7 @@ __global__ void selftest_log_guard_kernel(int site, unsigned long long *stats, f
 __global__ void selftest_nsdiv_kernel(unsigned long long *out, int iters);
 __global__ void selftest_div_kernel(const sea_gt_tables *t, unsigned long long *mismatches);
 __global__ void rfft256_kernel(const float *in, float *out, long long nframes, const sea_fft_tables *t);
+__global__ void rfft_any_kernel(float *x, const unsigned *sched, long long nframes);
 __global__ void compceps_kernel(CepsArgs a);
 __global__ void afe_ceps_kernel(AfeArgs a); /* WaveProc + CompCeps, one wave per cepstral frame */
 __global__ void afe_vad_kernel(AfeArgs a);  /* PostProc + frame-dropping VAD + flush, one wave per utterance */

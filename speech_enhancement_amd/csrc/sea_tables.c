@@ -667,3 +667,178 @@ void sea_ns16k_fft_host(float *x512)
     }
     memcpy(x512, x, sizeof x);
 }
+
+/* ---- rfft (x, n, m), any size (sea_tables.h) ------------------------------------------------------------------- */
+typedef struct {
+    unsigned *w;
+    unsigned long n;
+} words_ctx;
+static void words_visit(int i, void *ctx)
+{
+    words_ctx *c = (words_ctx *)ctx;
+    c->w[c->n++] = (unsigned)i;
+}
+static unsigned float_bits(float f)
+{
+    unsigned u;
+    memcpy(&u, &f, sizeof u);
+    return u;
+}
+
+unsigned *sea_rfft_schedule(int n, int m, unsigned long *n_words)
+{
+    unsigned *w;
+    unsigned long cap, at;
+    int i, j, k, n2;
+    words_ctx c;
+    if (n_words) *n_words = 0;
+    if (n < 2 || n > SEA_RFFT_MAXN || (n & (n - 1)) != 0 || m < 1 || m > 14 || (1 << m) > n) return NULL;
+    /* header + rev + length-two list + per level (block list <= n / 4, twiddles <= n / 2 words): generous bound */
+    cap = SEA_RFFT_HDR + (unsigned long)n + (unsigned long)n / 2 + (unsigned long)m * ((unsigned long)n / 2 + (unsigned long)n / 2 + 8) + 64;
+    w = (unsigned *)calloc(cap, sizeof *w);
+    if (!w) return NULL;
+    w[0] = (unsigned)n;
+    w[1] = (unsigned)m;
+    at = SEA_RFFT_HDR;
+    /* the digit-reverse counter (rfft.c:57-79) run on the indices: pos[p] = input element that ends at place p */
+    w[2] = (unsigned)at;
+    {
+        unsigned *pos = (unsigned *)malloc((size_t)n * sizeof *pos);
+        int jj = 0, kk;
+        if (!pos) {
+            free(w);
+            return NULL;
+        }
+        for (i = 0; i < n; i++) pos[i] = (unsigned)i;
+        for (i = 0; i < n - 1; i++) {
+            if (i < jj) {
+                const unsigned x = pos[jj];
+                pos[jj] = pos[i];
+                pos[i] = x;
+            }
+            kk = n >> 1;
+            while (kk <= jj && kk > 0) { /* (kk > 0 only guards the n = 2 corner, where the reference's loop ends with i) */
+                jj -= kk;
+                kk >>= 1;
+            }
+            jj += kk;
+        }
+        for (i = 0; i < n; i++) w[at + pos[i]] = (unsigned)i;
+        free(pos);
+        at += (unsigned long)n;
+    }
+    /* length-two butterflies (:82-96) */
+    w[3] = (unsigned)at;
+    c.w = w + at;
+    c.n = 0;
+    for_each_block(n, 2, 1, words_visit, &c);
+    w[4] = (unsigned)c.n;
+    at += c.n;
+    /* L-shaped levels (:99-179) */
+    for (k = 1, n2 = 2; k < m; k++) {
+        float e;
+        int n8;
+        n2 <<= 1;
+        n8 = n2 >> 3;
+        w[5 + 3 * k] = (unsigned)at;
+        c.w = w + at;
+        c.n = 0;
+        for_each_block(n, n2, 0, words_visit, &c);
+        w[6 + 3 * k] = (unsigned)c.n;
+        at += c.n;
+        w[7 + 3 * k] = (unsigned)at;
+        e = (float)((kPi * 2) / n2); /* :105 */
+        for (j = 1; j < n8; j++) {
+            const float a = j * e, a3 = 3 * a; /* :133-138: float angles, double cos / sin, stored as float */
+            w[at + 4 * (unsigned long)j + 0] = float_bits((float)cos((double)a));
+            w[at + 4 * (unsigned long)j + 1] = float_bits((float)sin((double)a));
+            w[at + 4 * (unsigned long)j + 2] = float_bits((float)cos((double)a3));
+            w[at + 4 * (unsigned long)j + 3] = float_bits((float)sin((double)a3));
+        }
+        at += 4ul * (unsigned long)(n8 > 0 ? n8 : 0);
+    }
+    if (at > cap) { /* cannot happen (bound above); never hand out an overrun table */
+        free(w);
+        return NULL;
+    }
+    if (n_words) *n_words = at;
+    return w;
+}
+
+/* The schedule walked on the host exactly as rfft_any_kernel walks it (items of a level in reverse order: the order
+ * within a level must not matter): lets a CPU test check rev / block lists / twiddles against the reference's loop nest
+ * for every size.  Returns 0, or 1 for a size sea_rfft_schedule refuses (x untouched). */
+int sea_rfft_schedule_host(float *x, int n, int m)
+{
+    unsigned long words = 0;
+    unsigned *w = sea_rfft_schedule(n, m, &words);
+    float *xs;
+    int i, k, n2;
+    long it;
+    if (!w) return 1;
+    xs = (float *)malloc((size_t)n * sizeof *xs);
+    if (!xs) {
+        free(w);
+        return 1;
+    }
+    for (i = 0; i < n; i++) xs[w[w[2] + i]] = x[i];
+    for (it = (long)w[4] - 1; it >= 0; it--) {
+        const int i0 = (int)w[w[3] + it];
+        const float a0 = xs[i0], a1 = xs[i0 + 1];
+        xs[i0] = a0 + a1;
+        xs[i0 + 1] = a0 - a1;
+    }
+    for (k = 1, n2 = 2; k < m; k++) {
+        int n4, n8, per;
+        const unsigned *blk;
+        const unsigned *tw;
+        n2 <<= 1;
+        n4 = n2 >> 2, n8 = n2 >> 3, per = n8 > 0 ? n8 : 1;
+        blk = w + w[5 + 3 * k];
+        tw = w + w[7 + 3 * k];
+        for (it = (long)w[6 + 3 * k] * per - 1; it >= 0; it--) {
+            const int b = (int)blk[it / per], j = (int)(it % per);
+            if (j == 0) {
+                {
+                    const int i1 = b, i3 = i1 + 2 * n4, i4 = i3 + n4;
+                    const float x1 = xs[i1], x3 = xs[i3], x4 = xs[i4], t1 = x4 + x3;
+                    xs[i4] = x4 - x3;
+                    xs[i3] = x1 - t1;
+                    xs[i1] = x1 + t1;
+                }
+                if (n4 != 1) {
+                    const int i1 = b + n8, i2 = i1 + n4, i3 = i2 + n4, i4 = i3 + n4;
+                    const float x1 = xs[i1], x2 = xs[i2], x3 = xs[i3], x4 = xs[i4];
+                    const float t1 = (float)((double)(x3 + x4) / 1.41421356237309504880);
+                    const float t2 = (float)((double)(x3 - x4) / 1.41421356237309504880);
+                    xs[i4] = x2 - t1;
+                    xs[i3] = -x2 - t1;
+                    xs[i2] = x1 - t2;
+                    xs[i1] = x1 + t2;
+                }
+            } else {
+                float cc1, ss1, cc3, ss3, t1, t2, t3, t4, t5, t6;
+                const int i1 = b + j, i2 = i1 + n4, i3 = i2 + n4, i4 = i3 + n4;
+                const int i5 = b + n4 - j, i6 = i5 + n4, i7 = i6 + n4, i8 = i7 + n4;
+                const float x1 = xs[i1], x2 = xs[i2], x3 = xs[i3], x4 = xs[i4], x5 = xs[i5], x6 = xs[i6], x7 = xs[i7], x8 = xs[i8];
+                memcpy(&cc1, &tw[4 * j], 4), memcpy(&ss1, &tw[4 * j + 1], 4), memcpy(&cc3, &tw[4 * j + 2], 4), memcpy(&ss3, &tw[4 * j + 3], 4);
+                t1 = x3 * cc1 + x7 * ss1, t2 = x7 * cc1 - x3 * ss1, t3 = x4 * cc3 + x8 * ss3, t4 = x8 * cc3 - x4 * ss3;
+                t5 = t1 + t3, t6 = t2 + t4;
+                t3 = t1 - t3;
+                t4 = t2 - t4;
+                xs[i3] = t6 - x6;
+                xs[i8] = x6 + t6;
+                xs[i7] = -x2 - t3;
+                xs[i4] = x2 - t3;
+                xs[i6] = x1 - t5;
+                xs[i1] = x1 + t5;
+                xs[i5] = x5 - t4;
+                xs[i2] = x5 + t4;
+            }
+        }
+    }
+    memcpy(x, xs, (size_t)n * sizeof *xs);
+    free(xs);
+    free(w);
+    return 0;
+}

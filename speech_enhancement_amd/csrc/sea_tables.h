@@ -114,6 +114,19 @@ typedef struct {
     double olaUp[160], olaDown[160];              /* 0.5(1+cos(n pi/160 + pi)), 0.5(1+cos(n pi/160)) */
 } sea_gt_tables;
 
+/* ---- rfft (x, n, m) for any size the reference's routine accepts (etsi/cpp/rfft.c:45-180) ----------------------------
+ * The drop-in symbol `rfft` takes n = 2^q and any order m with 2^m <= n (the reference only ever passes (256, 8) and, in
+ * the 16 k-native variant, (512, 8): order 8 on length 512, the last level never runs).  sea_rfft_schedule() unrolls the
+ * routine's loop nest for one (n, m) into flat tables of 32-bit words for the one-workgroup kernel rfft_any_kernel:
+ *   word 0 n, 1 m, 2 offset of rev[n] (input element e goes to place rev[e]: the digit-reverse counter, :57-79),
+ *   3 offset / 4 count of the length-two butterflies' first elements (:82-96),
+ *   for level k = 1 .. m-1 (n2 = 2^(k+1)):  5+3k offset / 6+3k count of the block starts i the is/id loops select
+ *   (:107-130), 7+3k offset of the twiddles (cc1, ss1, cc3, ss3 as float bits for j = 0 .. n8-1; j = 0 unused; :133-138).
+ * Returns a malloc'd array (caller frees) and its length in words, or NULL for a size the routine cannot take. */
+enum { SEA_RFFT_MAXN = 16384, SEA_RFFT_HDR = 64 };
+unsigned *sea_rfft_schedule(int n, int m, unsigned long *n_words);
+int sea_rfft_schedule_host(float *x, int n, int m); /* the schedule walked on the CPU (tests) */
+
 /* ---- the 16 k-native NoiseSup variant behind the reference's batch plug-in symbols (SURVEY 8(f) #4;
  * function/20141106_speech_enhancement/aurora_etsi/NoiseSup.h:36-53, NoiseSup.cpp:912-1407) ------------------------- */
 enum {

@@ -35,13 +35,14 @@ def etsi_denoise(x, fill=0):
     return out
 
 
-def rfft(x):
-    """void rfft(float*, 256, 8): returns Re(0..128), Im(127..1)."""
+def rfft(x, m=None):
+    """void rfft(float*, n, m) (etsi/cpp/rfft.h:19): returns Re(0..n/2), Im(n/2-1..1); m defaults to log2 n."""
     lib = _lib.load()
     y = np.array(x, dtype=np.float32, copy=True)
-    if y.size != 256:
-        raise ValueError("rfft: only n=256 is on the hot path")
-    lib.rfft(_np_ptr(y), 256, 8)
+    n = int(y.size)
+    if n < 2 or n & (n - 1):
+        raise ValueError("rfft: n must be a power of two")
+    lib.rfft(_np_ptr(y), n, int(m) if m is not None else n.bit_length() - 1)
     return y
 
 
@@ -332,6 +333,18 @@ def rfft_batch(frames):
     frames = frames.contiguous()
     out = torch.empty_like(frames)
     _lib.check(lib.sea_rfft256_batch(_dptr(frames), _dptr(out), frames.shape[0], _stream_ptr()), "sea_rfft256_batch")
+    return out
+
+
+def rfft_any_batch(frames, m=None):
+    """frames: float32 tensor [k, n] on the GPU -> rfft (x, n, m) of every row, any size the reference's routine takes
+    (etsi/cpp/rfft.c:45-180: n a power of two, 2^m <= n; m defaults to log2 n)."""
+    lib = _lib.load()
+    out = frames.contiguous().clone()
+    n = int(out.shape[1])
+    if m is None:
+        m = n.bit_length() - 1
+    _lib.check(lib.sea_rfft_batch(_dptr(out), n, int(m), out.shape[0], _stream_ptr()), "sea_rfft_batch")
     return out
 
 

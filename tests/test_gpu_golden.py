@@ -84,6 +84,33 @@ def test_golden_rfft():
     assert np.array_equal(one.view(np.uint32), g["rfft"][5].view(np.uint32))
 
 
+def test_golden_rfft_every_size():
+    """The drop-in symbol void rfft(float*, int, int) (etsi/cpp/rfft.h:19) and its device-pointer batch form for every
+    (n, m) of tests/golden/rfft_sizes_golden.npz -- n = 2 .. 16384 and orders below log2 n, incl. the variant's
+    rfft (x, 512, 8) -- bit-identical to what the reference's own routine produced; a size the routine cannot take leaves
+    x untouched and the process alive (round 3 abort()ed)."""
+    import ctypes
+    import speech_enhancement_amd as sea
+    torch = _torch()
+    lib = sea.load()
+    g = np.load(os.path.join(GOLD, "rfft_sizes_golden.npz"))
+    sizes = sorted({tuple(int(v) for v in k.split("_")[1:]) for k in g.files if k.startswith("in_")})
+    for n, m in sizes:
+        x, want = g[f"in_{n}_{m}"], g[f"out_{n}_{m}"]
+        got = sea.rfft_any_batch(torch.from_numpy(x).cuda(), m).cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"sea_rfft_batch, rfft (x, {n}, {m})"
+        one = np.array(x[-1], dtype=np.float32, copy=True)
+        lib.rfft(one.ctypes.data_as(ctypes.c_void_p), n, m)
+        assert np.array_equal(one.view(np.uint32), want[-1].view(np.uint32)), f"rfft (x, {n}, {m})"
+    many = np.tile(g["in_512_8"][1], (3000, 1))            # more frames than workgroups: the grid-stride loop
+    got = sea.rfft_any_batch(torch.from_numpy(many).cuda(), 8).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), np.tile(g["out_512_8"][1], (3000, 1)).view(np.uint32))
+    keep = np.arange(24, dtype=np.float32)
+    for n, m in ((24, 3), (16, 5)):
+        lib.rfft(keep.ctypes.data_as(ctypes.c_void_p), n, m)
+        assert np.array_equal(keep, np.arange(24, dtype=np.float32)) and b"rfft" in lib.sea_last_error()
+
+
 def test_golden_compceps_frames():
     import speech_enhancement_amd as sea
     torch = _torch()

@@ -211,6 +211,12 @@ def test_bench_starts_its_own_ranks(tmp_path):
     from speech_enhancement_amd import corpus
     assert j["n_gpus"] == 2 and j["seconds_max"] == 2.0
     assert j["total_frames"] == 3 * sum(corpus.utterance_length(u) // 80 for u in range(32))
+    # beside the weak-scaled headline every --gpus N run carries BASELINE configs[4]: the WHOLE 100 000-utterance corpus
+    # cut into N shards, one per rank (strong scaling) -- what a driver-run SCALE measures for N = 1, 2, 4, 8
+    c4 = j["configs4"]
+    assert c4["n_gpus"] == 2 and c4["scaling"] == "strong" and c4["utterances_rank0"] == 50000 and c4["seconds_max"] == 3.0
+    assert c4["total_frames"] == 2 * sum(corpus.utterance_length(u) // 80 for u in range(100000))
+    assert abs(c4["frames_rank0"] * 2 * 2 / c4["total_frames"] - 1) < 1e-3   # the two shards are balanced by samples
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--corpus-utts",
                         "100000", "--rehearse-cpu"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr

@@ -39,11 +39,10 @@ def parse_max(path, counter):
     return out
 
 
-def valu_issue(sq1, mix1):
+def valu_issue(sq1, mix1, k="ns_denoise_pipe_kernel"):
     """(vector instructions, priced issue clocks) per launch of the headline kernel from the SQ passes: every
     instruction at the f32 cost, f64 ones at the f64 cost, transcendentals at theirs.  (Packed-f32 instructions have
     no counter of their own and are priced as plain f32: the figure is a LOWER bound of the issue time.)"""
-    k = "ns_denoise_pipe_kernel"
     total = parse(sq1, "SQ_INSTS_VALU").get(k)  # minimum over the dispatches = the plain launches, as for the traffic
     if not total:
         return None, None
@@ -56,6 +55,11 @@ def valu_issue(sq1, mix1):
 
 def main():
     import bench
+    big = None
+    if "--big" in sys.argv:   # --big <fetch> <write> <sq1> <mix1>: the configs[4] form's own passes
+        i = sys.argv.index("--big")
+        big = sys.argv[i + 1:i + 5]
+        del sys.argv[i:]
     fetch, write = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE")
     keys = {"ns_denoise_pipe_kernel": "ns_denoise_kernel_bytes_per_launch", "resynth_fused_kernel": "resynth_bytes_per_launch",
             "compceps_kernel": "compceps_bytes_per_launch", "rfft256_kernel": "rfft256_bytes_per_launch",
@@ -82,6 +86,16 @@ def main():
         if insts:
             j["ns_valu_insts_per_launch"] = insts
             j["ns_valu_issue_clk_per_launch"] = clk
+    if big and all(os.path.exists(b) for b in big):
+        kb = "ns_denoise_pipe_big_kernel"
+        bf, bw = parse(big[0], "FETCH_SIZE"), parse(big[1], "WRITE_SIZE")
+        if kb in bf and kb in bw:
+            j["ns_big_bytes_per_launch"] = int(2 * bf[kb] * 1024 + bw[kb] * 1024)
+            j["fetch_kib"][kb], j["write_kib"][kb] = bf[kb], bw[kb]
+        insts, clk = valu_issue(big[2], big[3], kb)
+        if insts:
+            j["ns_big_valu_insts_per_launch"] = insts
+            j["ns_big_valu_issue_clk_per_launch"] = clk
     with open(sys.argv[3], "w") as f:
         json.dump(j, f, indent=1)
     print(json.dumps({k: v for k, v in j.items() if k.endswith("per_launch")}))
