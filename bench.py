@@ -373,12 +373,27 @@ def cpu_baseline(batch, n_sample, threads):
         res["reference_build"] = "the reference's etsi/cpp/*.c, gcc -O2 -ffp-contract=off (oracle/_ref)"
         if side:
             res["threads16"]["reference_value"] = _time_cpu(ref.lib, "ref_etsi_denoise", utts, side)[0]
+    # A box can show every CPU in the affinity mask and still hold the process to a share of them (cgroup cpu.max: 16 CPUs'
+    # worth on the 1-GPU box): 256 runnable threads under a 16-CPU quota are throttled and SLOWER than 16.  The baseline is
+    # what the host can do for this process: the best figure over both thread counts and both builds; `cores` names the
+    # thread count it was reached with, `all_cores` / `threads16` keep every measurement.
+    res["all_cores"] = {"threads": cores, "parity_build_value": res["parity_build_value"],
+                        "speed_build_value": res.get("speed_build_value"), "reference_value": res.get("reference_value")}
+    if side:
+        best16 = max(v for v in res["threads16"].values() if v)
+        res["threads16"]["threads"] = side
+        if best16 > best:
+            best, res["cores"] = best16, side
+            for k in ("parity_build_value", "speed_build_value", "reference_value"):
+                if res["threads16"].get(k):
+                    res[k] = res["threads16"][k]
     res["value"] = best
     frames = int(sum(len(u) // 80 for u in utts))
     res["sample"] = (f"the first {len(utts)} utterances of the shard ({frames} frames per pass), {passes}+ passes per build "
-                     f"(2 to warm up, then ~2 s worth) on {cores} threads = every CPU this process may run on, utterances "
-                     "pulled from a shared counter (oracle/cpu_pool.c); value = the faster of the port's two builds; "
-                     "threads16 = the same on 16 threads (the figure of rounds 1-3)")
+                     f"(one pass to warm up, two for an estimate, then ~2 s worth), utterances pulled from a shared counter "
+                     f"(oracle/cpu_pool.c), on {usable} threads = every CPU this process may run on (all_cores) and on 16 "
+                     f"(threads16, the figure of rounds 1-3); value = the fastest of the port's builds over both, reached on "
+                     f"{res['cores']} threads; cgroup_cpu_quota = the CPUs' worth of time the box grants this process")
     return res, outs
 
 

@@ -235,6 +235,10 @@ int sea_ns_streams_push_fd(const float *d_in, float *d_out, int *d_produced, uns
 int sea_ns16k_streams_push(const float *d_in, float *d_out, int *d_produced, unsigned char *d_flags, int *d_frame_counter,
                            float *d_wiener, float *d_state, int n_streams, int nframes, int reset, void *stream);
 int sea_ns16k_state_floats(void);
+/* kernel form of sea_ns16k_streams_push for later calls: 0 = four pipelined wavefronts per stream (default), 1 = one
+ * wavefront per stream (round 3's form, kept for A/B; SEA_NS16K_KERNEL=single makes it the initial form).  Same arithmetic,
+ * same state blob: a stream may change forms between two pushes.  form < 0 only reads; returns the previous form. */
+int sea_ns16k_kernel_form(int form);
 /* its host-side tables as the reference's init code lays them out (for checks against the oracle) */
 int sea_ns16k_tables_host(float *sigWindow480, float *irWindow17, int *gammaStart25, float *gamma25x128, float *idct25x25);
 /* and its table-driven transform schedule (what the kernel walks) run on the host, in place on 512 floats: rfft (x, 512, 8) */

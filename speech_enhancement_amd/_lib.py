@@ -59,6 +59,7 @@ PROTOTYPES = {
     "sea_ns_state_floats": (_i, []),
     "sea_ns16k_streams_push": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sea_ns16k_state_floats": (_i, []),
+    "sea_ns16k_kernel_form": (_i, [_i]),
     "sea_ns16k_tables_host": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "sea_ns16k_fft_host": (None, [_vp]),
     "etsi_denoise_mapping_global_init": (_i, [_vp, _vp]),

@@ -143,6 +143,8 @@ int ns_launch(const sea::NsBatchArgs &a, int form, hipStream_t stream)
 
 using namespace sea_capi;
 
+extern "C" int sea_ns16k_kernel_form(int form);
+
 extern "C" {
 
 const char *sea_last_error(void) { return last_error(); }
@@ -774,13 +776,33 @@ int sea_ns16k_streams_push(const float *d_in, float *d_out, int *d_produced, uns
     a.nframes = nframes;
     a.reset = reset;
     a.n_streams = n_streams;
-    constexpr int G = sea::kNs16StreamsPerGroup;
-    hipLaunchKernelGGL(sea::ns16k_stream_kernel, dim3((n_streams + G - 1) / G), dim3(64 * G), 0, (hipStream_t)stream, a);
+    /* SEA_NS16K_KERNEL=single: round 3's one-wavefront-per-stream form (kept for A/B); default: four pipelined waves per
+     * stream (ns16k_pipe_kernel.hip).  Same arithmetic, same state blob: a stream may change forms between two pushes. */
+    if (sea_ns16k_kernel_form(-1) == 1) {
+        constexpr int G = sea::kNs16StreamsPerGroup;
+        hipLaunchKernelGGL(sea::ns16k_stream_kernel, dim3((n_streams + G - 1) / G), dim3(64 * G), 0, (hipStream_t)stream, a);
+    } else {
+        constexpr int G = sea::kNs16PipeStreamsPerGroup;
+        hipLaunchKernelGGL(sea::ns16k_pipe_kernel, dim3((n_streams + G - 1) / G), dim3(256 * G), 0, (hipStream_t)stream, a);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int sea_ns16k_state_floats(void) { return sea::kNs16StateFloats; }
+
+/* 0: four pipelined waves per stream (default); 1: one wave per stream (round 3's form; SEA_NS16K_KERNEL=single sets it as
+ * the initial value).  form < 0 only reads.  Returns the previous form. */
+int sea_ns16k_kernel_form(int form)
+{
+    static std::atomic<int> g_form{[] {
+        const char *e = getenv("SEA_NS16K_KERNEL");
+        return (e && !strcmp(e, "single")) ? 1 : 0;
+    }()};
+    const int prev = g_form.load();
+    if (form == 0 || form == 1) g_form.store(form);
+    return prev;
+}
 
 int sea_ns16k_tables_host(float *sigWindow480, float *irWindow17, int *gammaStart25, float *gamma25x128, float *idct25x25)
 {

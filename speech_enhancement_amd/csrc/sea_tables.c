@@ -522,6 +522,181 @@ static void item_visit(int i, void *ctx)
     for (j = 1; j < c->n8; j++) slot_put(c, SEA16_BF_TWIDDLE, ((unsigned)j << 16) | (unsigned)i);
 }
 
+
+/* ---- tables of the PIPELINED kernel's transform wave (csrc/ns16k_pipe_kernel.hip) ----------------------------------
+ * rfft (x, 512, 8) with a register-resident start: lane l owns the places 8l .. 8l+7 of the digit-reversed order, i.e.
+ * the input elements bitrev6(l) + 64 bitrev3(j) (rev[] is the 9-bit reversal), so that the length-2 butterflies, the
+ * n2 = 4 and the n2 = 8 levels touch one lane's registers only, gated by the reference's is/id schedule; the levels
+ * n2 = 16 .. 256 go through LDS, ONE work item per lane and level -- a PAIR (plain butterfly on i + k n4, pi/4 butterfly
+ * on i + n8 + k n4) or a TWIDDLED butterfly -- dealt alternately to the two 32-lane halves, on a work area that is
+ * XOR-swizzled per 32-word block (SEA16_SWZ, found by tools/ns16k_swizzle_search.py: 800 -> 242 bank passes per
+ * transform, floor 192). */
+static const unsigned char kSwz16[16] = SEA16_SWZ;
+static unsigned swz16(unsigned word) { return (word ^ kSwz16[(word >> 5) & 15]) * 4u; } /* byte offset */
+typedef struct {
+    unsigned char mark[SEA16_NFFT];
+} mark16_ctx;
+static void mark16_visit(int i, void *ctx) { ((mark16_ctx *)ctx)->mark[i] = 1; }
+typedef struct {
+    int base[64], n;
+} list16_ctx;
+static void list16_visit(int i, void *ctx)
+{
+    list16_ctx *l = (list16_ctx *)ctx;
+    if (l->n >= 64) abort();
+    l->base[l->n++] = i;
+}
+
+static void build_ns16k_pipe(sea_ns16k_tables *t)
+{
+    sea_ns16k_pipe_tables *p = &t->pipe;
+    mark16_ctx len2, len4, len8;
+    int l, j, q, s;
+    memset(&len2, 0, sizeof len2);
+    memset(&len4, 0, sizeof len4);
+    memset(&len8, 0, sizeof len8);
+    for_each_block(SEA16_NFFT, 2, 1, mark16_visit, &len2);
+    for_each_block(SEA16_NFFT, 4, 0, mark16_visit, &len4);
+    for_each_block(SEA16_NFFT, 8, 0, mark16_visit, &len8);
+    for (l = 0; l < SEA_LANES; l++) {
+        unsigned fl = 0;
+        for (j = 0; j < 8; j++) {
+            const unsigned e = bitrev((unsigned)l, 6) + 64u * bitrev((unsigned)j, 3);
+            if (t->rev[e] != 8 * l + j) abort(); /* the head's element map IS the digit-reverse counter's */
+            p->src8[j][l] = (unsigned short)e;
+            p->win8[j][l] = t->sigWindow[e]; /* 0 beyond 479 (the kernel writes literal zeros there, as the reference pads) */
+        }
+        for (q = 0; q < 4; q++) {
+            if (len2.mark[8 * l + 2 * q]) fl |= 1u << q;
+            p->head8Addr[q][l] = swz16(8u * l + 2u * q) | (swz16(8u * l + 2u * q + 1u) << 16);
+        }
+        if (len4.mark[8 * l]) fl |= 16u;
+        if (len4.mark[8 * l + 4]) fl |= 32u;
+        if (len8.mark[8 * l]) fl |= 64u;
+        p->head8Flags[l] = fl;
+    }
+    for (s = 0; s < SEA16_PIPE_LEVELS; s++) {
+        const int k = s + 3, n2 = 2 << k, n4 = n2 >> 2, n8 = n2 >> 3;
+        list16_ctx blocks;
+        int b, item = 0, op;
+        unsigned words[64][8];
+        blocks.n = 0;
+        for_each_block(SEA16_NFFT, n2, 0, list16_visit, &blocks);
+        for (l = 0; l < SEA_LANES; l++) p->kind[s][l] = SEA_BF_NONE;
+        for (b = 0; b < blocks.n; b++)
+            for (j = 1; j < n8; j++, item++) {
+                const int lane = (item & 1) * 32 + (item >> 1), i = blocks.base[b];
+                if (item >= 64) abort();
+                p->kind[s][lane] = SEA_BF_TWIDDLE;
+                for (op = 0; op < 4; op++) {
+                    words[lane][op] = (unsigned)(i + j + op * n4);
+                    words[lane][4 + op] = (unsigned)(i + n4 - j + op * n4);
+                    p->tw[s][op][lane] = t->fftTw[k][j][op];
+                }
+            }
+        for (b = 0; b < blocks.n; b++, item++) {
+            const int lane = (item & 1) * 32 + (item >> 1), i = blocks.base[b];
+            if (item >= 64) abort();
+            p->kind[s][lane] = SEA_BF_PAIR;
+            for (op = 0; op < 4; op++) {
+                words[lane][op] = (unsigned)(i + op * n4);
+                words[lane][4 + op] = (unsigned)(i + n8 + op * n4);
+            }
+        }
+        for (l = 0; l < SEA_LANES; l++) {
+            /* an idle lane fetches what the first lane of its half fetches (identical addresses broadcast: no bank pass of
+             * its own) and stores nothing */
+            const int src = (p->kind[s][l] == SEA_BF_NONE) ? (l & 32) : l;
+            if (p->kind[s][src] == SEA_BF_NONE) abort();
+            for (q = 0; q < 4; q++) p->addr[s][q][l] = swz16(words[src][2 * q]) | (swz16(words[src][2 * q + 1]) << 16);
+        }
+    }
+    /* FFTtoPSD (NoiseSup.cpp:240-261): value b = lane + 64 h needs x[2b], x[2b+1], x[512-2b] (b = 0: unused, element 0),
+     * x[511-2b]; value 128 is x[256] squared */
+    for (l = 0; l < SEA_LANES; l++)
+        for (q = 0; q < 2; q++) {
+            const unsigned b = (unsigned)l + 64u * (unsigned)q;
+            p->psd[q][0][l] = swz16(2 * b) | (swz16(2 * b + 1) << 16);
+            p->psd[q][1][l] = swz16((SEA16_NFFT - 2 * b) % SEA16_NFFT) | (swz16(SEA16_NFFT - 1 - 2 * b) << 16);
+        }
+    p->nyq = swz16(256);
+}
+
+/* rfft (x, 512, 8) walked on the host through the PIPELINED kernel's tables exactly as its transform wave walks them
+ * (tests): x512 in natural order in, the reference's output order out. */
+void sea_ns16k_pipe_fft_host(float *x512)
+{
+    static sea_ns16k_tables t;
+    static int ready = 0;
+    float work[SEA16_NFFT], out[SEA16_NFFT];
+    int l, j, s, q;
+    if (!ready) {
+        sea_build_ns16k_tables(&t);
+        ready = 1;
+    }
+    {
+        const sea_ns16k_pipe_tables *p = &t.pipe;
+        for (l = SEA_LANES - 1; l >= 0; l--) {
+            float e[8];
+            const unsigned fl = p->head8Flags[l];
+            for (j = 0; j < 8; j++) e[j] = x512[p->src8[j][l]];
+            for (q = 0; q < 4; q++)
+                if (fl & (1u << q)) {
+                    const float a = e[2 * q], b = e[2 * q + 1];
+                    e[2 * q] = a + b;
+                    e[2 * q + 1] = a - b;
+                }
+            for (q = 0; q < 2; q++)
+                if (fl & (16u << q)) {
+                    const float g0 = e[4 * q], g2 = e[4 * q + 2], g3 = e[4 * q + 3], t1 = g3 + g2;
+                    e[4 * q + 3] = g3 - g2;
+                    e[4 * q + 2] = g0 - t1;
+                    e[4 * q] = g0 + t1;
+                }
+            if (fl & 64u) {
+                const float x1 = e[0], x3 = e[4], x4 = e[6], x5 = e[1], x6 = e[3], x7 = e[5], x8 = e[7], t1 = x4 + x3;
+                const float u1 = (float)((double)(x7 + x8) / 1.41421356237309504880), u2 = (float)((double)(x7 - x8) / 1.41421356237309504880);
+                e[6] = x4 - x3;
+                e[4] = x1 - t1;
+                e[0] = x1 + t1;
+                e[7] = x6 - u1;
+                e[5] = -x6 - u1;
+                e[3] = x5 - u2;
+                e[1] = x5 + u2;
+            }
+            for (q = 0; q < 4; q++) {
+                work[(p->head8Addr[q][l] & 0xffffu) / 4] = e[2 * q];
+                work[(p->head8Addr[q][l] >> 16) / 4] = e[2 * q + 1];
+            }
+        }
+        for (s = 0; s < SEA16_PIPE_LEVELS; s++)
+            for (l = SEA_LANES - 1; l >= 0; l--) {
+                unsigned a[8];
+                float x[8], o[8];
+                if (p->kind[s][l] == SEA_BF_NONE) continue;
+                for (q = 0; q < 4; q++) a[2 * q] = (p->addr[s][q][l] & 0xffffu) / 4, a[2 * q + 1] = (p->addr[s][q][l] >> 16) / 4;
+                for (q = 0; q < 8; q++) x[q] = work[a[q]];
+                if (p->kind[s][l] == SEA_BF_TWIDDLE) {
+                    const float cc1 = p->tw[s][0][l], ss1 = p->tw[s][1][l], cc3 = p->tw[s][2][l], ss3 = p->tw[s][3][l];
+                    float t1 = x[2] * cc1 + x[6] * ss1, t2 = x[6] * cc1 - x[2] * ss1, t3 = x[3] * cc3 + x[7] * ss3, t4 = x[7] * cc3 - x[3] * ss3;
+                    const float t5 = t1 + t3, t6 = t2 + t4;
+                    t3 = t1 - t3;
+                    t4 = t2 - t4;
+                    o[2] = t6 - x[5], o[7] = x[5] + t6, o[6] = -x[1] - t3, o[3] = x[1] - t3;
+                    o[5] = x[0] - t5, o[0] = x[0] + t5, o[4] = x[4] - t4, o[1] = x[4] + t4;
+                } else {
+                    const float t1 = x[3] + x[2];
+                    const float u1 = (float)((double)(x[6] + x[7]) / 1.41421356237309504880), u2 = (float)((double)(x[6] - x[7]) / 1.41421356237309504880);
+                    o[3] = x[3] - x[2], o[2] = x[0] - t1, o[0] = x[0] + t1, o[1] = x[1];
+                    o[7] = x[5] - u1, o[6] = -x[5] - u1, o[5] = x[4] - u2, o[4] = x[4] + u2;
+                }
+                for (q = 0; q < 8; q++) work[a[q]] = o[q];
+            }
+    }
+    for (l = 0; l < SEA16_NFFT; l++) out[l] = work[swz16((unsigned)l) / 4];
+    memcpy(x512, out, sizeof out);
+}
+
 void sea_build_ns16k_tables(sea_ns16k_tables *t)
 {
     int start[SEA16_NGAM], i, j, k, n2;
@@ -581,15 +756,22 @@ void sea_build_ns16k_tables(sea_ns16k_tables *t)
         ctx.n8 = n2 >> 3;
         memset(ctx.count, 0, sizeof ctx.count);
         for_each_block(SEA16_NFFT, n2, 0, item_visit, &ctx);
-        e = (float)((kPi * 2) / n2);
-        for (j = 1; j < (n2 >> 3); j++) {
-            const float a = j * e, a3 = 3 * a;
-            t->fftTw[k][j][0] = cosf(a);
-            t->fftTw[k][j][1] = sinf(a);
-            t->fftTw[k][j][2] = cosf(a3);
-            t->fftTw[k][j][3] = sinf(a3);
-        }
+        (void)e;
     }
+    /* the twiddles (rfft.cpp:135-144, float overloads of cos / sin) are generated CONSTANTS, not calls of the host's
+     * cosf / sinf at initialisation: the result must not depend on the box's libm (tools/gen_ns16k_twiddles.py) */
+    {
+        static const struct {
+            int pass, j;
+            float v[4];
+        } kTw[] = {
+#include "ns16k_twiddles.inc"
+        };
+        unsigned q;
+        for (q = 0; q < sizeof kTw / sizeof kTw[0]; q++)
+            for (i = 0; i < 4; i++) t->fftTw[kTw[q].pass][kTw[q].j][i] = kTw[q].v[i];
+    }
+    build_ns16k_pipe(t);
 }
 
 void sea_ns16k_plain_tables(float *sigWindow480, float *irWindow17, int *gammaStart25, float *gamma25x128, float *idct25x25)

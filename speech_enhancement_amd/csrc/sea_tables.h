@@ -147,6 +147,22 @@ enum {
  * Entry: valid << 31 | j << 16 | block start i. */
 enum { SEA16_BF_LEN2 = 0, SEA16_BF_PLAIN = 1, SEA16_BF_PI4 = 2, SEA16_BF_TWIDDLE = 3 };
 
+/* the pipelined kernel's transform wave (sea_tables.c::build_ns16k_pipe, ns16k_pipe_kernel.hip) */
+enum { SEA16_PIPE_LEVELS = 5 }; /* n2 = 16 .. 256 through LDS; length-2, n2 = 4, n2 = 8 on registers */
+#define SEA16_SWZ {0, 19, 4, 3, 4, 29, 17, 0, 25, 8, 25, 16, 23, 30, 23, 12} /* word i of the work area sits at i ^ SEA16_SWZ[i >> 5] */
+typedef struct {
+    unsigned head8Flags[SEA_LANES];                       /* bits 0..3 length-2 on (8l+2p, +1); 4, 5: n2 = 4 on 8l / 8l+4; 6: n2 = 8 on the block */
+    unsigned head8Addr[4][SEA_LANES];                     /* swizzled byte offsets of places 8l+2q | 8l+2q+1 << 16 */
+    unsigned kind[SEA16_PIPE_LEVELS][SEA_LANES];          /* SEA_BF_NONE / SEA_BF_PAIR / SEA_BF_TWIDDLE */
+    unsigned addr[SEA16_PIPE_LEVELS][4][SEA_LANES];       /* the eight operands' byte offsets, two per word */
+    float tw[SEA16_PIPE_LEVELS][4][SEA_LANES];
+    unsigned psd[2][2][SEA_LANES];                        /* value l + 64 q: x[2b] | x[2b+1] << 16, x[512-2b] | x[511-2b] << 16 */
+    unsigned nyq;                                         /* x[256] */
+    unsigned pad[3];
+    float win8[8][SEA_LANES];                             /* window weight of element src8[j][l] */
+    unsigned short src8[8][SEA_LANES];                    /* bitrev6(l) + 64 bitrev3(j): the input element at place 8l + j */
+} sea_ns16k_pipe_tables;
+
 typedef struct {
     float sigWindow[SEA16_NFFT];                          /* Hanning(480), 0 beyond */
     unsigned short rev[SEA16_NFFT];                       /* where rfft.cpp's digit-reverse counter puts input element i */
@@ -157,9 +173,11 @@ typedef struct {
     float irWin[16];                                      /* [j] = Hanning(17)[8 + j], j = 0..8 */
     float eps;
     float pad[15];
+    sea_ns16k_pipe_tables pipe;
 } sea_ns16k_tables;
 void sea_build_ns16k_tables(sea_ns16k_tables *t);
 void sea_ns16k_fft_host(float *x512); /* the table-driven transform on the host (tests) */
+void sea_ns16k_pipe_fft_host(float *x512); /* the same through the pipelined kernel's tables (tests) */
 void sea_ns16k_plain_tables(float *sigWindow480, float *irWindow17, int *gammaStart25, float *gamma25x128, float *idct25x25);
 
 void sea_build_ns_tables(sea_ns_tables *t);

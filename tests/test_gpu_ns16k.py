@@ -87,6 +87,36 @@ def test_ns16k_streams_vs_oracle_chunked(oracle):
     assert gated[0] == 2 and gated[2] > 10 and gated[5] >= 50      # the gate cases really occur
 
 
+def test_ns16k_kernel_forms_agree_and_share_the_state_blob(oracle):
+    """The pipelined form (four waves per stream, two streams per workgroup: csrc/ns16k_pipe_kernel.hip) and round 3's
+    one-wave form are the same arithmetic on the same state blob: every combination of forms over two pushes, an ODD
+    number of streams (the second stream slot of the last workgroup is padding), and pushes of one and two frames (shorter
+    than the pipeline is deep) must all equal the oracle's func_Wiener on the whole signal."""
+    import speech_enhancement_amd as sea
+    torch = _torch()
+    lib = sea.load()
+    nfr = 90
+    x = np.concatenate([_streams(nfr), _streams(nfr)[:1] * np.float32(0.5)])     # seven streams
+    want = [oracle.ns16k_new().push(x[b]) for b in range(len(x))]
+    fr = torch.from_numpy(x.reshape(len(x), nfr, 160)).cuda()
+    prev = lib.sea_ns16k_kernel_form(-1)
+    try:
+        for forms, cuts in (((0, 0), (0, 41, nfr)), ((1, 0), (0, 41, nfr)), ((0, 1), (0, 41, nfr)), ((1, 1), (0, 41, nfr)),
+                            ((0, 0, 0, 0, 0, 0), (0, 1, 2, 4, 5, 40, nfr)), ((0, 1, 0, 1, 0), (0, 3, 7, 8, 30, nfr))):
+            state, parts = None, []
+            for form, a, b in zip(forms, cuts[:-1], cuts[1:]):
+                lib.sea_ns16k_kernel_form(form)
+                r = sea.ns16k_streams_push(fr[:, a:b].contiguous(), state=state)
+                state = r["state"]
+                parts.append({k: v.cpu().numpy() for k, v in r.items() if k != "state"})
+            torch.cuda.synchronize()
+            for b in range(len(x)):
+                got = {k: np.concatenate([p[k][b] for p in parts]) for k in parts[0]}
+                _compare(got, want[b], nfr, f"forms {forms} cuts {cuts} stream {b}")
+    finally:
+        lib.sea_ns16k_kernel_form(prev)
+
+
 def test_ns16k_golden_no_oracle_in_the_loop():
     """The HIP path against the committed fixture tests/golden/ns16k_golden.npz (written by the restatement: a regression
     anchor, see oracle/gen_golden.py).  The transform's twiddles are the HOST libm's cosf / sinf (the C++ float overloads

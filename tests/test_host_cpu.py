@@ -84,6 +84,17 @@ def test_ns16k_host_tables_and_schedule_match_oracle(oracle):
         y = x.copy()
         lib.sea_ns16k_fft_host(y.ctypes.data_as(ctypes.c_void_p))
         assert np.array_equal(y.view(np.uint32), oracle.ns16k_rfft(x).view(np.uint32))
+        z = x.copy()   # the pipelined kernel's tables: register-resident start, one item per lane and level, swizzled work area
+        lib.sea_ns16k_pipe_fft_host(z.ctypes.data_as(ctypes.c_void_p))
+        assert np.array_equal(z.view(np.uint32), y.view(np.uint32))
+    # the twiddles are generated constants (csrc/ns16k_twiddles.inc), not the host libm's cosf / sinf at initialisation: both
+    # table walks against what the REFERENCE's own rfft.cpp (compiled here) made of the fixture's frames
+    g = np.load(os.path.join(ROOT, "tests", "golden", "aurora_golden.npz"))
+    for x, want in zip(g["frames"], g["rfft512_8"]):
+        for fn in (lib.sea_ns16k_fft_host, lib.sea_ns16k_pipe_fft_host):
+            y = np.array(x, dtype=np.float32, copy=True)
+            fn(y.ctypes.data_as(ctypes.c_void_p))
+            assert np.array_equal(y.view(np.uint32), want.view(np.uint32))
 
 
 def test_no_cpu_fallback_without_gpu():
