@@ -109,10 +109,14 @@ void gammatone_host_tables(float *cf64, float *bw64, float *midEar64)
  *                chain of frames)                                     SEA_NS_KERNEL=pipe6
  *   <= 4 per CU  four waves, transform address tables in VGPRs       SEA_NS_KERNEL=pipe
  *   more         four waves, tables in LDS: six workgroups per CU     SEA_NS_KERNEL=big
+ *   (never)      two utterances per workgroup, lane-sparse phases packed   SEA_NS_KERNEL=pair (experiment, slower)
  * SEA_NS_KERNEL=single: one wave per utterance (the streaming plug-in's kernel), for A/B. */
 int ns_pick_form(int n_inflight, int n_cu)
 {
     const int forced = sea_ns_kernel_form(-1);
+    /* (form 5, two utterances per workgroup with their lane-sparse phases packed into one wave -- ns_pipe2_kernel.hip -- has
+     * 22 % fewer vector instructions per frame and is slower: 434 against 465 M frames/s on the configs[4] shard; never
+     * chosen here, see that file's header) */
     return forced ? forced : (n_inflight <= 2 * n_cu ? 3 : (n_inflight <= 4 * n_cu ? 2 : 4));
 }
 
@@ -120,7 +124,7 @@ int ns_launch(const sea::NsBatchArgs &a, int form, hipStream_t stream)
 {
     if (a.n_utt <= 0) return 0;
     if (a.state) { /* time slices: the four-wave forms only */
-        if (form == 4)
+        if (form == 4 || form == 5)
             hipLaunchKernelGGL(sea::ns_denoise_pipe_big_slice_kernel, dim3(a.n_utt), dim3(256), 0, stream, a);
         else
             hipLaunchKernelGGL(sea::ns_denoise_pipe_slice_kernel, dim3(a.n_utt), dim3(256), 0, stream, a);
@@ -133,6 +137,8 @@ int ns_launch(const sea::NsBatchArgs &a, int form, hipStream_t stream)
         hipLaunchKernelGGL(sea::ns_denoise_pipe6_kernel, dim3(a.n_utt), dim3(384), 0, stream, a);
     else if (form == 4)
         hipLaunchKernelGGL(sea::ns_denoise_pipe_big_kernel, dim3(a.n_utt), dim3(256), 0, stream, a);
+    else if (form == 5)
+        hipLaunchKernelGGL(sea::ns_denoise_pipe_pair_kernel, dim3((a.n_utt + 1) / 2), dim3(sea::ns_pair_threads()), 0, stream, a);
     else
         hipLaunchKernelGGL(sea::ns_denoise_pipe_kernel, dim3(a.n_utt), dim3(256), 0, stream, a);
     HIP_TRY(hipGetLastError());
@@ -192,15 +198,29 @@ static int ns_form()
         if (e && !strcmp(e, "pipe")) f = 2;
         if (e && !strcmp(e, "pipe6")) f = 3;
         if (e && !strcmp(e, "big")) f = 4;
+        if (e && !strcmp(e, "pair")) f = 5;
         g_ns_form.store(f);
     }
     return f;
 }
 
+/* diagnostic (tools/): resident workgroups per CU of NoiseSup kernel form f as the runtime computes them (0: unknown form) */
+int sea_debug_ns_occupancy(int form)
+{
+    int n = 0;
+    hipError_t e = hipErrorInvalidValue;
+    if (form == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sea::ns_denoise_pipe_kernel, 256, 0);
+    if (form == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sea::ns_denoise_pipe6_kernel, 384, 0);
+    if (form == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sea::ns_denoise_pipe_big_kernel, 256, 0);
+    if (form == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sea::ns_denoise_pipe_pair_kernel, sea::ns_pair_threads(), 0);
+    if (form == 16) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sea::ns16k_pipe_kernel, 512, 0);
+    return e == hipSuccess ? n : -1;
+}
+
 int sea_ns_kernel_form(int form)
 {
     const int prev = ns_form();
-    if (form >= 0 && form <= 4) g_ns_form.store(form);
+    if (form >= 0 && form <= 5) g_ns_form.store(form);
     return prev;
 }
 

@@ -856,3 +856,14 @@ __global__ void __launch_bounds__(256 * p16::kStreams, 4) ns16k_pipe_kernel(Ns16
 }
 
 } // namespace sea
+
+#ifdef SEA16P_TIMING
+extern "C" int sea_debug_ns16p_timing(unsigned long long *out16, int reset)
+{
+    if (reset) {
+        unsigned long long z[16] = {0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(sea::p16::g_ns16p_timing), z, sizeof z);
+    }
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(sea::p16::g_ns16p_timing), 16 * sizeof(unsigned long long));
+}
+#endif

@@ -64,6 +64,9 @@ struct NsConst {
 #ifndef SEA_NS_FAST_DIV
 #define SEA_NS_FAST_DIV 1
 #endif
+#ifndef SEA_NS_STEADY
+#define SEA_NS_STEADY 1 /* branch-free FilterCalc of (bin lane, bin 64) side by side in the forms without register pairs */
+#endif
 
 struct NsRegs {
     /* per bin: [stage]; "Lo" = bin lane (0..63), "Hi" = bin 64 (meaningful in lane 0) */
@@ -559,6 +562,34 @@ __device__ __forceinline__ float filter_bin(float P, float nSig, float &noise, f
         }
     }
     return gain_bin<FAST>(P, nSig, noise, den);
+}
+
+/* filter_bin<ST, true> without control flow (ST 1: valid for nb >= 11 only: noise_track1's steady-state branch), the reference's
+ * `if (flagVAD == 0)` as a select of the same values: two or three such chains (bins 0..63 | bin 64; utterance a | b) written
+ * back to back sit in ONE basic block and the scheduler interleaves them -- a wave issues a dependent instruction every
+ * ~8 clk, an independent one every ~2. */
+template <int ST>
+__device__ __forceinline__ float filter_steady(float P, float nSig, float &noise, float &den, int nb, int flagVAD, float eps)
+{
+    if (ST == 1) { /* noise_track1<true>, nb >= 11 (NoiseSup.c:492-508) */
+        float n2 = noise * noise;
+        const float r1 = ns_div(P, ns_rcp(P + n2));
+        const float r2 = ns_div(P, ns_rcp(n2));
+        const double inv = ns_inv64(1.0 + 0.1 * (double)r2);
+        const float upd = (float)(0.9 + 0.1 * (double)r1 * (1.0 + inv));
+        n2 *= upd;
+        n2 = SEA_SQRT(n2);
+        noise = (n2 < eps) ? eps : n2;
+    }
+    nSig = SEA_SQRT(nSig);
+    P = SEA_SQRT(P);
+    if (ST == 0) { /* VAD-gated noise tracking in magnitude, :531-546 */
+        const float lambda = (nb < 100) ? 1 - 1 / (float)nb : (float)0.99;
+        const float n = lambda * noise + (1 - lambda) * P;
+        const float nn = (n < eps) ? eps : n;
+        noise = (flagVAD == 0) ? nn : noise;
+    }
+    return gain_bin<true>(P, nSig, noise, den);
 }
 
 /* VAD frame log-energy (NoiseSup.c:386-391) from 64 + sum of the 80 squared samples: depends on
@@ -1176,6 +1207,9 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
         if (SEA_NS_PAIR_BINS && RL) { /* not in the 80-VGPR form: the pairs cost registers there (9 spills, -4 %) */
             filter_bins_fast<ST>(PLo, PHi, nSigLo, nSigHi, s.noiseLo[ST], s.noiseHi[ST], s.denLo[ST], s.denHi[ST],
                                  nb16, s.flagVAD, C.eps, WLo, WHi);
+        } else if (SEA_NS_STEADY && (ST == 0 || nb16 >= 11)) { /* the two chains in one basic block (filter_steady) */
+            WLo = filter_steady<ST>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
+            WHi = filter_steady<ST>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);
         } else {
             WLo = filter_bin<ST, true>(PLo, nSigLo, s.noiseLo[ST], s.denLo[ST], nb16, s.flagVAD, C.eps);
             WHi = filter_bin<ST, true>(PHi, nSigHi, s.noiseHi[ST], s.denHi[ST], nb16, s.flagVAD, C.eps);

@@ -144,6 +144,9 @@ __global__ void subband_kernel(SubbandArgs a);
 __global__ void ns_denoise_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_big_kernel(NsBatchArgs a); /* lower-register form for > 4 utterances per CU */
+__global__ void ns_denoise_pipe_pair_kernel(NsBatchArgs a);
+/* two utterances per workgroup, lane-sparse phases packed (ns_pipe2_kernel.hip: experiment) */
+int ns_pair_threads(); /* threads per workgroup of that kernel */
 __global__ void ns_denoise_pipe_fd_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_slice_kernel(NsBatchArgs a);     /* time slices: state in / out (NsBatchArgs::state) */
 __global__ void ns_denoise_pipe_big_slice_kernel(NsBatchArgs a);

@@ -529,7 +529,7 @@ static void item_visit(int i, void *ctx)
  * n2 = 4 and the n2 = 8 levels touch one lane's registers only, gated by the reference's is/id schedule; the levels
  * n2 = 16 .. 256 go through LDS, ONE work item per lane and level -- a PAIR (plain butterfly on i + k n4, pi/4 butterfly
  * on i + n8 + k n4) or a TWIDDLED butterfly -- dealt alternately to the two 32-lane halves, on a work area that is
- * XOR-swizzled per 32-word block (SEA16_SWZ, found by tools/ns16k_swizzle_search.py: 800 -> 242 bank passes per
+ * XOR-swizzled per 32-word block (SEA16_SWZ, found by tools/ns16k_swizzle_search.py: 800 -> 204 bank passes per
  * transform, floor 192). */
 static const unsigned char kSwz16[16] = SEA16_SWZ;
 static unsigned swz16(unsigned word) { return (word ^ kSwz16[(word >> 5) & 15]) * 4u; } /* byte offset */

@@ -149,7 +149,7 @@ enum { SEA16_BF_LEN2 = 0, SEA16_BF_PLAIN = 1, SEA16_BF_PI4 = 2, SEA16_BF_TWIDDLE
 
 /* the pipelined kernel's transform wave (sea_tables.c::build_ns16k_pipe, ns16k_pipe_kernel.hip) */
 enum { SEA16_PIPE_LEVELS = 5 }; /* n2 = 16 .. 256 through LDS; length-2, n2 = 4, n2 = 8 on registers */
-#define SEA16_SWZ {0, 19, 4, 3, 4, 29, 17, 0, 25, 8, 25, 16, 23, 30, 23, 12} /* word i of the work area sits at i ^ SEA16_SWZ[i >> 5] */
+#define SEA16_SWZ {0, 9, 22, 3, 10, 31, 5, 20, 18, 25, 16, 21, 11, 6, 12, 29} /* word i of the work area sits at i ^ SEA16_SWZ[i >> 5] */
 typedef struct {
     unsigned head8Flags[SEA_LANES];                       /* bits 0..3 length-2 on (8l+2p, +1); 4, 5: n2 = 4 on 8l / 8l+4; 6: n2 = 8 on the block */
     unsigned head8Addr[4][SEA_LANES];                     /* swizzled byte offsets of places 8l+2q | 8l+2q+1 << 16 */
