@@ -540,8 +540,8 @@ def also_lines(batch, ids, device, steps):
          "sea::ns_denoise_pipe_fd_kernel + sea::afe_ceps_kernel + sea::afe_vad_kernel", "afe_bytes_per_launch")
     del outb, f32, flags, fcc, f15
 
-    # the 16 k-native NoiseSup variant behind etsi_denoise_mapping_* (a side path: one wave per stream,
-    # exact divisions throughout), one stream per utterance of the shard, 400 frames of 160 int16-valued samples each
+    # the 16 k-native NoiseSup variant behind etsi_denoise_mapping_* (round 4: four pipelined waves per stream,
+    # two streams per workgroup), one stream per utterance of the shard, 400 frames of 160 int16-valued samples each
     B, nf = batch.n_utt, 400
     gen = torch.Generator(device=device)
     gen.manual_seed(16)
@@ -558,7 +558,7 @@ def also_lines(batch, ids, device, steps):
                                           w16.data_ptr(), st16.data_ptr(), B, nf, 1, st) == 0
     ker, wall = timed_steps(run16, max(2, steps // 2), 1)
     assert int(pr16.sum().item()) == B * (nf - 4)
-    # the same samples as twice the streams of half the length: two wavefronts per SIMD instead of one
+    # the same samples as twice the streams of half the length (two rounds of workgroups instead of one)
     B2, nf2 = 2 * B, nf // 2
 
     def run16b():
@@ -567,8 +567,8 @@ def also_lines(batch, ids, device, steps):
     st16b = torch.zeros((B2, lib.sea_ns16k_state_floats()), dtype=torch.float32, device=device)
     ker2, wall2 = timed_steps(run16b, max(2, steps // 2), 1)
     line("NoiseSup, 16 k-native variant", f"SURVEY 8(f) #4: {B} streams x {nf} frames of 160 samples through the variant behind "
-         "etsi_denoise_mapping_* (window 480, rfft (x, 512, 8), 25 gammatone-shaped windows), one wavefront per stream",
-         B * nf, "frames/s", B * nf * (2 * 640 + 100 + 9), ker, wall, "sea::ns16k_stream_kernel", "ns16k_bytes_per_launch",
+         "etsi_denoise_mapping_* (window 480, rfft (x, 512, 8), 25 gammatone-shaped windows), four pipelined wavefronts per stream",
+         B * nf, "frames/s", B * nf * (2 * 640 + 100 + 9), ker, wall, "sea::ns16k_pipe_kernel", "ns16k_bytes_per_launch",
          {"rtf": wall / (B * nf * 160 / 16000.0),
           "as_twice_the_streams_of_half_the_length": {"streams": B2, "frames": nf2, "value": B2 * nf2 / wall2, "unit": "frames/s",
                                                       "ms_per_step": wall2 * 1e3, "avg_launch_ms": ker2 * 1e3}})

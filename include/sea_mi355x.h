@@ -304,6 +304,12 @@ int sea_selftest_log_guard(int site, unsigned long long *stats8, float *hits3, i
 /* host pipelines (csrc/hostpipe.hip): from the nth hipEventQuery of the process on, every query reports a device fault
  * (0: off).  The pipelines must then return 1 -- the reference's fault code -- instead of polling for ever. */
 int sea_selftest_hostpipe_fault(long long nth_query);
+/* the 16 k-native variant's pieces that the reference's own rfft.cpp + MelProc.cpp pin (tests/golden/aurora_golden.npz), run on
+ * the device by the very functions the pipelined kernel calls (host pointers): rfft (x, 512, 8) of nfft frames from both of the
+ * transform wave's work areas ([nfft][512] each), DoGamma of ngain vectors of 129 gains ([ngain][25]) and rows 0..8 of
+ * DoGammaIDCT of those ([ngain][9], before the filter window) */
+int sea_selftest_ns16k_pieces(const float *frames512, int nfft, float *fft512_a, float *fft512_b, const float *gains129, int ngain,
+                              float *gamma25, float *idct9);
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,7 @@ PROTOTYPES = {
     "sea_selftest_log_sites": (_i, [_vp, _vp, _vp, _i]),
     "sea_selftest_log_guard": (_i, [_i, _vp, _vp, _i]),
     "sea_selftest_hostpipe_fault": (_i, [ctypes.c_longlong]),
+    "sea_selftest_ns16k_pieces": (_i, [_vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
 }
 
 _lib = None

@@ -811,6 +811,37 @@ int sea_ns16k_streams_push(const float *d_in, float *d_out, int *d_produced, uns
 
 int sea_ns16k_state_floats(void) { return sea::kNs16StateFloats; }
 
+/* the 16 k-native variant's transform, DoGamma and DoGammaIDCT on the device, piece by piece (host pointers): see
+ * ns16k_selftest_kernel; fft512_a / _b: [nfft][512], gamma25: [ngain][25], idct9: [ngain][9] (rows 0..8, before the window) */
+int sea_selftest_ns16k_pieces(const float *frames512, int nfft, float *fft512_a, float *fft512_b, const float *gains129, int ngain,
+                              float *gamma25, float *idct9)
+{
+    if (nfft < 0 || ngain < 0) return fail("sea_selftest_ns16k_pieces: negative count");
+    DeviceCtx *c;
+    if (ctx(&c)) return 1;
+    DevBuf<float> dfr, da, db, dg, dgam, did;
+    HIP_TRY(dfr.alloc((size_t)(nfft > 0 ? nfft : 1) * 512));
+    HIP_TRY(da.alloc((size_t)(nfft > 0 ? nfft : 1) * 512));
+    HIP_TRY(db.alloc((size_t)(nfft > 0 ? nfft : 1) * 512));
+    HIP_TRY(dg.alloc((size_t)(ngain > 0 ? ngain : 1) * 129));
+    HIP_TRY(dgam.alloc((size_t)(ngain > 0 ? ngain : 1) * 25));
+    HIP_TRY(did.alloc((size_t)(ngain > 0 ? ngain : 1) * 9));
+    if (nfft) HIP_TRY(hipMemcpy(dfr.p, frames512, (size_t)nfft * 512 * sizeof(float), hipMemcpyHostToDevice));
+    if (ngain) HIP_TRY(hipMemcpy(dg.p, gains129, (size_t)ngain * 129 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(sea::ns16k_selftest_kernel, dim3(1), dim3(64), 0, nullptr, c->ns16, dfr.p, nfft, da.p, db.p, dg.p, ngain, dgam.p, did.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (nfft) {
+        HIP_TRY(hipMemcpy(fft512_a, da.p, (size_t)nfft * 512 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(fft512_b, db.p, (size_t)nfft * 512 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    if (ngain) {
+        HIP_TRY(hipMemcpy(gamma25, dgam.p, (size_t)ngain * 25 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(idct9, did.p, (size_t)ngain * 9 * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
 /* 0: four pipelined waves per stream (default); 1: one wave per stream (round 3's form; SEA_NS16K_KERNEL=single sets it as
  * the initial value).  form < 0 only reads.  Returns the previous form. */
 int sea_ns16k_kernel_form(int form)

@@ -156,6 +156,8 @@ __global__ void ns_stream_kernel(NsStreamArgs a);
 __global__ void ns16k_stream_kernel(Ns16StreamArgs a);
 __global__ void ns16k_pipe_kernel(Ns16StreamArgs a); /* four pipelined waves per stream, two streams per workgroup */
 constexpr int kNs16PipeStreamsPerGroup = 2;
+__global__ void ns16k_selftest_kernel(const sea_ns16k_tables *t, const float *frames, int nfft, float *outA, float *outB, const float *gains,
+                                      int ngain, float *gamma25, float *idct9);
 __global__ void ns_stream_fd_kernel(NsStreamArgs a);
 __global__ void selftest_pi4_kernel(unsigned long long *mismatches);
 __global__ void selftest_dc_kernel(const float *dif, const float *y0, float *out, int *fellback, int ncases);

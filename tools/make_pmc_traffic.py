@@ -64,7 +64,7 @@ def main():
     keys = {"ns_denoise_pipe_kernel": "ns_denoise_kernel_bytes_per_launch", "resynth_fused_kernel": "resynth_bytes_per_launch",
             "compceps_kernel": "compceps_bytes_per_launch", "rfft256_kernel": "rfft256_bytes_per_launch",
             "subband_kernel": "subband_bytes_per_launch", "irm_target_kernel": "irm_bytes_per_launch",
-            "ns16k_stream_kernel": "ns16k_bytes_per_launch"}
+            "ns16k_pipe_kernel": "ns16k_bytes_per_launch"}
     j = {"_comment": "HBM traffic per launch on the bench.py workloads (configs[1] corpus, 1024 utterances; rfft256: 2^18 frames), "
                      "from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes = 2 * FETCH_KiB * 1024 + WRITE_KiB * 1024 "
                      "(gfx950 FETCH_SIZE correction, see tools/make_pmc_traffic.py); per kernel the minimum over its dispatches "
