@@ -620,7 +620,14 @@ int sea_irm_target_batch(const short *d_pure64, const short *d_noise64, const lo
     a.fft = &c->ns->fft;
     a.n_utt = n_utt;
     a.window = window;
-    hipLaunchKernelGGL(sea::irm_target_kernel, dim3((unsigned)n_utt * 64u), dim3(64), 0, (hipStream_t)stream, a);
+    static const bool dual = [] {
+        const char *e = getenv("SEA_IRM_KERNEL");
+        return e && !strcmp(e, "dual");
+    }();
+    if (dual)
+        hipLaunchKernelGGL(sea::irm_target_dual_kernel, dim3((unsigned)n_utt * 64u), dim3(64), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(sea::irm_target_kernel, dim3((unsigned)n_utt * 64u), dim3(256), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -138,7 +138,8 @@ struct IrmArgs {
     int n_utt;
     int window;                    /* 0 rectangular, 1 Hamming, 2 Hanning */
 };
-__global__ void irm_target_kernel(IrmArgs a);
+__global__ void irm_target_kernel(IrmArgs a);      /* round 4: per-lane codelet, lane = (polyphase component, frame) */
+__global__ void irm_target_dual_kernel(IrmArgs a); /* rounds 2-3: LDS dual transform per frame (A/B) */
 
 __global__ void subband_kernel(SubbandArgs a);
 __global__ void ns_denoise_kernel(NsBatchArgs a);

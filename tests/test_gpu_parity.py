@@ -621,7 +621,7 @@ def test_irm_target_vs_oracle(oracle):
     import speech_enhancement_amd as sea
     from speech_enhancement_amd import corpus
     torch = _torch()
-    lens = [4800, 320, 320 + 160 * 3 + 11]
+    lens = [4800, 320, 320 + 160 * 3 + 11, 160 * 150 + 5]   # 149 frames: ten 16-frame tiles over the four waves of a workgroup
     clean = [corpus.synth_utterance(120 + i, L) for i, L in enumerate(lens)]
     noise = [(corpus.synth_utterance(140 + i, L).astype(np.int32) // 3).astype(np.int16) for i, L in enumerate(lens)]
     cb, nb = sea.PackedBatch.from_arrays(clean), sea.PackedBatch.from_arrays(noise)

@@ -87,6 +87,26 @@ def main():
                          "algorithmic_bytes_per_step": alg, "avg_step_ms": ker * 1e3}}), flush=True)
         del out
 
+    if "irm" in what:   # SURVEY 8(f) #2 on two different subband blocks (as bench.py's also-line)
+        sub = torch.zeros(batch.total * 64, dtype=torch.int16, device=dev)
+        sub2 = torch.zeros(batch.total * 64, dtype=torch.int16, device=dev)
+        keep = batch.data
+        batch.data = torch.flip(keep, dims=[0]).contiguous()
+        sea.subband_batch(batch, out=sub2)
+        batch.data = keep
+        sea.subband_batch(batch, out=sub)
+        torch.cuda.synchronize()
+        wall, ker = timed(lambda: sea.irm_target_batch(batch, sub, sub2), args.steps)
+        hops = int(np.sum((np.asarray(batch.host_lengths) - 320) // 160 + 1))
+        alg = hops * (2 * 128 * 160 + 256)
+        print(json.dumps({
+            "metric": "IRM target hop-frames/sec (x 64 channels)", "value": hops / wall, "unit": "hop-frames/s", "ms_per_step": wall * 1e3,
+            "config": {"workload": f"SURVEY 8(f) #2: {args.utts} utterances, {hops} frames x 64 channels from two subband blocks"},
+            "roofline": {"bound": "hbm", "kernel": "sea::irm_target_kernel", "achieved": alg / ker / 1e9, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": alg / ker / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_step": alg,
+                         "avg_step_ms": ker * 1e3}}), flush=True)
+        del sub, sub2
+
     if "ceps" in what:
         out, f32, first = sea.ns_denoise_batch(batch, want_f32=True)
         torch.cuda.synchronize()
