@@ -733,6 +733,31 @@ def end_to_end(batch, steps):
             assert lib.sea_denoise_utterances(pin, pout, lens, n) == 0
             per.append(time.perf_counter() - ta)
         wall = float(np.median(per))
+        # the packed-pinned form: the caller's samples already sit where the copy engine reads them (sea_packed_*): the run
+        # below is what a file driver's device thread pays per list -- uploads, launches, downloads, no pack / unpack copies
+        pk = lib.sea_packed_create()
+        per_pk = []
+        assert lib.sea_packed_plan(pk, lens, n) == 0, lib.sea_last_error()
+        K = lib.sea_packed_slices(pk)
+        for u, x in enumerate(ins):
+            pi, po, cnt = (ctypes.c_void_p * K)(), (ctypes.c_void_p * K)(), (ctypes.c_long * K)()
+            k = lib.sea_packed_segments(pk, u, pi, po, cnt, K)
+            pos = 0
+            for i in range(k):
+                ctypes.memmove(pi[i], x.ctypes.data + 2 * pos, 2 * cnt[i])
+                pos += cnt[i]
+        for _ in range(2):
+            assert lib.sea_packed_denoise(pk) == 0, lib.sea_last_error()
+        for _ in range(max(steps, 8)):
+            ta = time.perf_counter()
+            assert lib.sea_packed_denoise(pk) == 0
+            per_pk.append(time.perf_counter() - ta)
+        wall_pk = float(np.median(per_pk))
+        # the last utterance's pieces against what sea_denoise_utterances left for it (same bits)
+        k = lib.sea_packed_segments(pk, n - 1, pi, po, cnt, K)
+        got = np.concatenate([np.ctypeslib.as_array(ctypes.cast(po[i], ctypes.POINTER(ctypes.c_short)), shape=(cnt[i],)) for i in range(k)])
+        packed_same = bool(np.array_equal(got, outs[n - 1][:got.size]))
+        lib.sea_packed_destroy(pk)
         # the reference's own calling pattern: one etsi_denoise(short*, short*, long) per utterance
         k = min(n, 64)
         fr1 = int(sum(x.size // 80 for x in ins[:k]))
@@ -757,6 +782,11 @@ def end_to_end(batch, steps):
                                    "ms_per_call_min_mean_max": [round(min(per) * 1e3, 3), round(float(np.mean(per)) * 1e3, 3), round(max(per) * 1e3, 3)],
                                    "what": f"sea_denoise_utterances on the {n} utterances of this shard in host memory, "
                                            f"{lib.sea_host_threads()} packing threads"},
+            "denoise_packed": {"value": batch.n_frames / wall_pk, "unit": "frames/s", "ms_per_call": wall_pk * 1e3,
+                               "same_bits_as_denoise_utterances": packed_same,
+                               "what": f"sea_packed_denoise on the same {n} utterances written into the library's pinned staging by the "
+                                       f"caller ({K} time slices): uploads, launches and downloads pipelined, no pack / unpack copies; "
+                                       f"median of {len(per_pk)} calls"},
             "etsi_denoise_per_utterance": {"value": fr1 / (per_call * k), "unit": "frames/s", "ms_per_call": per_call * 1e3,
                                            "what": f"{k} sequential etsi_denoise() calls, mean {fr1 / k:.0f} frames each"},
             "ns_stream_push": {"value": per_frame * 1e6, "unit": "us per 80-sample frame",

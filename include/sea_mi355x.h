@@ -165,6 +165,22 @@ long long sea_resynth_scratch_bytes(long long total_padded_samples, int n_utt);
  * etsi_denoise does; results do not depend on either cut. */
 int sea_denoise_utterances(const short *const *in, short *const *out, const long *lengths, int n_utt);
 int sea_host_threads(void); /* size of that pool */
+/* NoiseSup from PINNED staging the caller fills and reads -- no pack / unpack copies (csrc/hostpipe.hip).  For a caller that
+ * produces its samples itself (a file reader) and consumes the results itself (a file writer):
+ *   p = sea_packed_create();                          a reusable staging set (pinned, portable across devices)
+ *   sea_packed_plan(p, lengths, n_utt);               lays the list out in time slices (as sea_denoise_utterances does inside)
+ *   k = sea_packed_segments(p, u, in, out, count, max);   utterance u = k pieces in time order (k <= sea_packed_slices(p)):
+ *                                                     write its samples into in[i][0 .. count[i]), i = 0..k-1
+ *   sea_packed_denoise(p);                            on a thread bound to a device (sea_init): 0, or 1 = fault
+ *   ... out[i][0 .. count[i]) is etsi_denoise's output for every whole frame of utterance u; the trailing lengths[u] % 80
+ *   samples belong to no piece (etsi_denoise never writes them).  A set may be planned again after it has been read. */
+typedef struct sea_packed sea_packed;
+sea_packed *sea_packed_create(void);
+void sea_packed_destroy(sea_packed *p);
+int sea_packed_plan(sea_packed *p, const long *lengths, int n_utt);
+int sea_packed_slices(const sea_packed *p);
+int sea_packed_segments(const sea_packed *p, int u, short **in_seg, short **out_seg, long *count, int max_seg);
+int sea_packed_denoise(sea_packed *p);
 /* NoiseSup + CompCeps from host buffers, the chain ParmInterface.c:275-293 ran before its author commented it out
  * (SURVEY 8(d) Config 1: a 4-s utterance gives 800 NoiseSup frames, 796 outputs, 794 cepstral frames): out as above;
  * ceps[u] receives n_ceps[u] rows of 14 floats (c1..c12, c0, logE), capacity max(lengths[u]/80 - 6, 0) rows. */

@@ -39,6 +39,12 @@ PROTOTYPES = {
     "sea_resynth_scratch_bytes": (_ll, [_ll, _i]),
     "sea_denoise_utterances": (_i, [_vp, _vp, _vp, _i]),
     "sea_host_threads": (_i, []),
+    "sea_packed_create": (_vp, []),
+    "sea_packed_destroy": (None, [_vp]),
+    "sea_packed_plan": (_i, [_vp, _vp, _i]),
+    "sea_packed_slices": (_i, [_vp]),
+    "sea_packed_segments": (_i, [_vp, _i, _vp, _vp, _vp, _i]),
+    "sea_packed_denoise": (_i, [_vp]),
     "sea_denoise_ceps_utterances": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     "sea_compceps_frame": (_i, [_vp, _vp]),
     "sea_resynth64": (_i, [_vp, _l, _vp, _i, _i, _vp]),

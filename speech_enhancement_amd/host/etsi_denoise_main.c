@@ -18,9 +18,13 @@
  * Here, one step coarser and with the file I/O taken off the GPU's critical path:
  *   reader threads   pull CHUNKS of the list from a shared counter, read their WAVs          -> queue
  *   device threads   one per device (sea_device_count(), or SEA_DEVICES=n; more threads than devices share them
- *                    round robin): sea_init(dev), then one sea_denoise_utterances per chunk  -> queue
+ *                    round robin): sea_init(dev), then one launch pipeline per chunk         -> queue
  *   writer threads   write the chunk's WAVs, free it
  * so chunk k+1 is being read and chunk k-1 written while chunk k is on a GPU; no data crosses between devices.
+ * Round 4: the samples travel WITHOUT pack / unpack copies (sea_packed_*): a reader probes the chunk's WAV headers, lets the
+ * library lay the chunk out in its pinned staging (sea_packed_plan) and freads every file straight into the pieces
+ * sea_packed_segments names; the device thread runs sea_packed_denoise; a writer fwrites the output pieces.  (--ceps keeps
+ * the pointer-array entry point sea_denoise_ceps_utterances; SEA_HOST_PACKED=0 switches the plain path back too.)
  *
  *   --dry-run   parse cfg/list/WAVs and report, no GPU work, nothing written
  *   --ceps      also write <id>_e_resynth.ceps next to each output WAV: the cepstra DoCompCeps gives on the denoised
@@ -42,7 +46,7 @@
 typedef struct {
     const sea_cfg *opts;
     char **ids;
-    int n_ids, chunk, dry, n_dev, ceps;
+    int n_ids, chunk, dry, n_dev, ceps, packed;
     FILE *Log;
     pthread_mutex_t mu; /* the shared chunk counter, stdout / Log lines, rc */
     int next, rc;
@@ -83,6 +87,10 @@ static void *reader(void *arg)
             set_rc(J, 1);
             break;
         }
+        if (J->packed) {
+            c->data_off = (long *)calloc((size_t)n, sizeof(long));
+            c->channels = (int *)calloc((size_t)n, sizeof(int));
+        }
         for (u = 0; u < n; u++) {
             int fs = 0;
             const char *id = J->ids[first + u];
@@ -92,6 +100,14 @@ static void *reader(void *arg)
             if (J->Log) fprintf(J->Log, "%s\n ", id);
             printf("%s %d\n", path, first + u);
             pthread_mutex_unlock(&J->mu);
+            if (J->packed) { /* header only: the samples are read once the library has laid the chunk out */
+                if (sea_wav_probe(path, &c->len[u], &fs, &c->data_off[u], &c->channels[u])) {
+                    fprintf(stderr, "ERROR:   cannot read %s\n", path);
+                    c->rc = 3;
+                    c->len[u] = 0;
+                }
+                continue;
+            }
             if (sea_wav_read(path, &c->in[u], &c->len[u], &fs)) {
                 fprintf(stderr, "ERROR:   cannot read %s\n", path);
                 c->rc = 3;
@@ -104,6 +120,30 @@ static void *reader(void *arg)
                 c->ceps[u] = (float *)calloc((size_t)(cap > 0 ? cap : 1) * 14, sizeof(float));
             }
             if (J->dry) printf("  %ld samples, %d Hz\n", c->len[u], fs);
+        }
+        if (J->packed && !c->rc) {
+            /* the library's pinned staging for this chunk; every file read straight into its pieces */
+            c->packed = sea_packed_create();
+            if (!c->packed || sea_packed_plan(c->packed, c->len, n)) {
+                fprintf(stderr, "ERROR:   %s\n", sea_last_error());
+                c->rc = 1;
+            } else {
+                const int K = sea_packed_slices(c->packed) > 0 ? sea_packed_slices(c->packed) : 1;
+                short **seg = (short **)malloc((size_t)K * sizeof *seg);
+                long *cnt = (long *)malloc((size_t)K * sizeof *cnt);
+                for (u = 0; u < n && seg && cnt; u++) {
+                    const int k = sea_packed_segments(c->packed, u, seg, NULL, cnt, K);
+                    if (k <= 0) continue; /* shorter than one frame: nothing to denoise */
+                    snprintf(path, sizeof path, "%s%s%s_noisy.wav", opts->outputDictionary, opts->save_noisy_dir, J->ids[first + u]);
+                    if (sea_wav_read_segs(path, c->data_off[u], c->channels[u], seg, cnt, k)) {
+                        fprintf(stderr, "ERROR:   cannot read %s\n", path);
+                        c->rc = 3;
+                    }
+                }
+                if (!seg || !cnt) c->rc = 1;
+                free(seg);
+                free(cnt);
+            }
         }
         if (c->rc) set_rc(J, c->rc);
         sea_queue_put(&J->to_device, c);
@@ -125,7 +165,7 @@ static void *device_thread(void *arg)
     }
     while ((c = sea_queue_get(&J->to_device)) != NULL) {
         if (ok && !J->dry && !c->rc) {
-            const int bad = J->ceps ? sea_denoise_ceps_utterances((const short *const *)c->in, c->out, c->ceps, c->n_ceps, c->len, c->n)
+            const int bad = c->packed ? sea_packed_denoise(c->packed) : J->ceps ? sea_denoise_ceps_utterances((const short *const *)c->in, c->out, c->ceps, c->n_ceps, c->len, c->n)
                                     : sea_denoise_utterances((const short *const *)c->in, c->out, c->len, c->n);
             if (bad) {
                 fprintf(stderr, "ERROR:   %s\n", sea_last_error());
@@ -151,7 +191,15 @@ static void *writer(void *arg)
         for (u = 0; u < c->n && !rc && !J->dry; u++) {
             snprintf(path, sizeof path, "%s%s%s_e_resynth.wav", opts->outputDictionary, opts->save_resynth_e_dir,
                      J->ids[c->first + u]);
-            if (sea_wav_write(path, c->out[u], c->len[u], 16000)) rc = 4;
+            if (c->packed) { /* the output pieces in time order, then the trailing partial frame as zeros */
+                const int K = sea_packed_slices(c->packed) > 0 ? sea_packed_slices(c->packed) : 1;
+                short **seg = (short **)malloc((size_t)K * sizeof *seg);
+                long *cnt = (long *)malloc((size_t)K * sizeof *cnt);
+                const int k = (seg && cnt) ? sea_packed_segments(c->packed, u, NULL, seg, cnt, K) : -1;
+                if (k < 0 || sea_wav_write_segs(path, seg, cnt, k, c->len[u] - c->len[u] / 80 * 80, 16000)) rc = 4;
+                free(seg);
+                free(cnt);
+            } else if (sea_wav_write(path, c->out[u], c->len[u], 16000)) rc = 4;
             if (!rc && J->ceps) {
                 FILE *f;
                 const int hdr[2] = {c->n_ceps[u], 14};
@@ -165,6 +213,10 @@ static void *writer(void *arg)
             }
         }
         if (rc) set_rc(J, rc);
+        if (c->packed) {
+            sea_packed_destroy(c->packed);
+            c->packed = NULL;
+        }
         sea_chunk_free(c);
     }
     return NULL;
@@ -199,6 +251,7 @@ int main(int argc, char *argv[])
         return 2;
     }
     if (!J.dry) n_dev = sea_device_count();
+    J.packed = !J.dry && !J.ceps && !((e = getenv("SEA_HOST_PACKED")) && e[0] == '0');
     n_thr = n_dev > 0 ? n_dev : 1;
     if ((e = getenv("SEA_DEVICES")) && atoi(e) > 0) n_thr = atoi(e);
     if (n_thr > MAX_THREADS) n_thr = MAX_THREADS;

@@ -117,6 +117,65 @@ bad:
     return 2;
 }
 
+int sea_wav_probe(const char *path, long *n, int *fs, long *data_off, int *channels)
+{
+    FILE *fp = fopen(path, "rb");
+    unsigned char h[12], ck[8], fmt[16];
+    int ch = 0, bits = 0, format = 0, have_fmt = 0;
+    *n = 0;
+    if (!fp) return 1;
+    if (fread(h, 1, 12, fp) != 12 || memcmp(h, "RIFF", 4) || memcmp(h + 8, "WAVE", 4)) goto bad;
+    while (fread(ck, 1, 8, fp) == 8) {
+        uint32_t size = rd32(ck + 4);
+        if (!memcmp(ck, "fmt ", 4)) {
+            if (size < 16 || fread(fmt, 1, 16, fp) != 16) goto bad;
+            format = rd16(fmt);
+            ch = rd16(fmt + 2);
+            *fs = (int)rd32(fmt + 4);
+            bits = rd16(fmt + 14);
+            have_fmt = 1;
+            fseek(fp, (long)(size - 16 + (size & 1)), SEEK_CUR);
+        } else if (!memcmp(ck, "data", 4)) {
+            long here, end;
+            if (!have_fmt || format != 1 || bits != 16 || ch < 1) goto bad;
+            here = ftell(fp);
+            fseek(fp, 0, SEEK_END);
+            end = ftell(fp);
+            if ((long)size > end - here) size = (uint32_t)(end - here); /* a truncated file holds what it holds */
+            *n = (long)(size / (2u * (unsigned)ch));
+            *data_off = here;
+            *channels = ch;
+            fclose(fp);
+            return 0;
+        } else
+            fseek(fp, (long)(size + (size & 1)), SEEK_CUR);
+    }
+bad:
+    fclose(fp);
+    return 2;
+}
+
+int sea_wav_read_segs(const char *path, long data_off, int channels, short *const *seg, const long *cnt, int nseg)
+{
+    FILE *fp = fopen(path, "rb");
+    int k, rc = 0;
+    if (!fp) return 1;
+    if (fseek(fp, data_off, SEEK_SET)) rc = 2;
+    for (k = 0; k < nseg && !rc; k++) {
+        if (channels == 1) { /* little-endian host: the samples go where they are used, one read per piece */
+            if (fread(seg[k], sizeof(short), (size_t)cnt[k], fp) != (size_t)cnt[k]) rc = 2;
+        } else {
+            long i;
+            unsigned char *raw = (unsigned char *)malloc((size_t)(cnt[k] ? cnt[k] : 1) * 2u * (unsigned)channels);
+            if (!raw || fread(raw, 2u * (unsigned)channels, (size_t)cnt[k], fp) != (size_t)cnt[k]) rc = 2;
+            for (i = 0; i < cnt[k] && !rc; i++) seg[k][i] = (short)rd16(raw + (size_t)i * 2u * (unsigned)channels);
+            free(raw);
+        }
+    }
+    fclose(fp);
+    return rc;
+}
+
 static void wr32(unsigned char *p, uint32_t v) { p[0] = v & 255; p[1] = (v >> 8) & 255; p[2] = (v >> 16) & 255; p[3] = (v >> 24) & 255; }
 static void wr16(unsigned char *p, uint16_t v) { p[0] = v & 255; p[1] = (v >> 8) & 255; }
 
@@ -149,6 +208,39 @@ int sea_wav_write(const char *path, const short *data, long n, int fs)
     }
     fclose(fp);
     return 0;
+}
+
+int sea_wav_write_segs(const char *path, short *const *seg, const long *cnt, int nseg, long n_zero_tail, int fs)
+{
+    FILE *fp = fopen(path, "wb");
+    unsigned char h[44];
+    long n = n_zero_tail, i;
+    int k, rc = 0;
+    static const short zeros[80] = {0};
+    if (!fp) {
+        fprintf(stderr, "Cannot write in the file %s\n", path);
+        return 1;
+    }
+    for (k = 0; k < nseg; k++) n += cnt[k];
+    memcpy(h, "RIFF", 4);
+    wr32(h + 4, (uint32_t)(36 + 2 * n));
+    memcpy(h + 8, "WAVEfmt ", 8);
+    wr32(h + 16, 16);
+    wr16(h + 20, 1);
+    wr16(h + 22, 1);
+    wr32(h + 24, (uint32_t)fs);
+    wr32(h + 28, (uint32_t)fs * 2u);
+    wr16(h + 32, 2);
+    wr16(h + 34, 16);
+    memcpy(h + 36, "data", 4);
+    wr32(h + 40, (uint32_t)(2 * n));
+    if (fwrite(h, 1, 44, fp) != 44) rc = 1;
+    for (k = 0; k < nseg && !rc; k++)
+        if (fwrite(seg[k], sizeof(short), (size_t)cnt[k], fp) != (size_t)cnt[k]) rc = 1;
+    for (i = n_zero_tail; i > 0 && !rc; i -= 80)
+        if (fwrite(zeros, sizeof(short), (size_t)(i < 80 ? i : 80), fp) != (size_t)(i < 80 ? i : 80)) rc = 1;
+    if (fclose(fp)) rc = 1;
+    return rc;
 }
 
 /* ---- Kaldi-style 64-column text matrices (show_IBM.cpp:194-208 writer, main.cpp:84-145 reader) ---- */
@@ -237,6 +329,8 @@ void sea_chunk_free(sea_chunk *c)
     free(c->mask);
     free(c->ceps);
     free(c->n_ceps);
+    free(c->data_off);
+    free(c->channels);
     free(c);
 }
 

@@ -33,6 +33,13 @@ void sea_free_list(char **ids, int n);
 /* Left channel of a PCM16 RIFF file.  Returns 0 and a malloc'ed buffer, or non-zero. */
 int sea_wav_read(const char *path, short **data, long *n, int *fs);
 int sea_wav_write(const char *path, const short *data, long n, int fs);
+/* The same in pieces, for staging the library lays out (sea_packed_segments): sea_wav_probe parses the header only (sample
+ * count per channel, rate, channel count, byte offset of the data); sea_wav_read_segs reads the first sum(cnt) samples of the
+ * left channel straight into seg[0][0..cnt[0]), seg[1][..], ... (mono files: one fread per piece, no intermediate buffer);
+ * sea_wav_write_segs writes a mono PCM16 file of sum(cnt) + n_zero_tail samples from such pieces. */
+int sea_wav_probe(const char *path, long *n, int *fs, long *data_off, int *channels);
+int sea_wav_read_segs(const char *path, long data_off, int channels, short *const *seg, const long *cnt, int nseg);
+int sea_wav_write_segs(const char *path, short *const *seg, const long *cnt, int nseg, long n_zero_tail, int fs);
 
 /* SURVEY 8(f) #2 -- the on-disk contract between feature extraction, the external DNN and resynth:
  * Kaldi-style text matrices of 64 columns.  sea_mask_text_write emits exactly what make_single_IBM
@@ -60,6 +67,10 @@ typedef struct sea_chunk {
     int *n_ceps;
     long *len;
     int rc;
+    struct sea_packed *packed; /* etsi: the library's pinned staging for this chunk (sea_packed_*), or NULL; the driver destroys it
+                                * before sea_chunk_free (this file does not link against the library) */
+    long *data_off;            /* etsi, packed: byte offset of the samples in the WAV file */
+    int *channels;
     struct sea_chunk *next;
 } sea_chunk;
 sea_chunk *sea_chunk_new(int first, int n, int with_mask, int with_ceps);

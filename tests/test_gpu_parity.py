@@ -329,6 +329,56 @@ def test_denoise_utterances_pipeline_any_chunking(oracle, monkeypatch):
         check(f"chunks of {mb} MB")
 
 
+def test_packed_pinned_entry_points(oracle, monkeypatch):
+    """sea_packed_*: the caller writes its samples into the pinned staging the library laid out (pieces in time order, one
+    per time slice the utterance reaches) and reads the results from the matching output pieces -- no pack / unpack copies
+    (what host/etsi_denoise_main.c's reader and writer threads do).  Every whole frame must equal the oracle's etsi_denoise,
+    for one slice and for several, with empty / sub-frame / all-zero utterances in the list, and a set must be reusable."""
+    import ctypes
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    _torch()
+    lib = sea.load()
+    rng = np.random.default_rng(23)
+    lens = [int(v) for v in rng.integers(0, 48000, 60)] + [0, 79, 80, 161, 32000, 32000, 31999]
+    utts = [corpus.synth_utterance(500 + i, L) for i, L in enumerate(lens)]
+    utts[7] = np.zeros(lens[7], np.int16)
+    want = [oracle.etsi_denoise(x) for x in utts]
+    n = len(utts)
+    p = lib.sea_packed_create()
+    assert p
+    try:
+        for slices in ("1", "3", None, "40"):
+            if slices is None:
+                monkeypatch.delenv("SEA_HOST_SLICES", raising=False)
+            else:
+                monkeypatch.setenv("SEA_HOST_SLICES", slices)
+            for rep in range(2):                                           # the same set planned and run twice
+                pl = (ctypes.c_long * n)(*lens)
+                assert lib.sea_packed_plan(p, pl, n) == 0, lib.sea_last_error()
+                K = lib.sea_packed_slices(p)
+                assert K >= 1
+                segs = []
+                for u, x in enumerate(utts):
+                    pin, pout, cnt = (ctypes.c_void_p * K)(), (ctypes.c_void_p * K)(), (ctypes.c_long * K)()
+                    k = lib.sea_packed_segments(p, u, pin, pout, cnt, K)
+                    assert sum(cnt[i] for i in range(k)) == lens[u] // 80 * 80, f"utterance {u}: pieces do not cover its whole frames"
+                    pos = 0
+                    for i in range(k):
+                        dst = np.ctypeslib.as_array(ctypes.cast(pin[i], ctypes.POINTER(ctypes.c_short)), shape=(cnt[i],))
+                        dst[:] = x[pos:pos + cnt[i]]
+                        pos += cnt[i]
+                    segs.append((k, pout, cnt))
+                assert lib.sea_packed_denoise(p) == 0, lib.sea_last_error()
+                for u, (k, pout, cnt) in enumerate(segs):
+                    got = np.concatenate([np.ctypeslib.as_array(ctypes.cast(pout[i], ctypes.POINTER(ctypes.c_short)), shape=(cnt[i],))
+                                          for i in range(k)] or [np.zeros(0, np.int16)])
+                    full = lens[u] // 80 * 80
+                    assert np.array_equal(got, want[u][:full]), f"{slices or 'default'} slices, run {rep}: utterance {u} (L={lens[u]}) differs"
+    finally:
+        lib.sea_packed_destroy(p)
+
+
 def test_host_pipeline_returns_fault_on_event_error(oracle, monkeypatch):
     """The three event-driven pipelines of csrc/hostpipe.hip poll hipEventQuery; any answer other than "done" / "not
     ready" must end the call with the reference's fault code 1 (etsi/cpp/AdvFrontEnd.c:205-209) -- not be polled for
