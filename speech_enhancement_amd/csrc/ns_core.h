@@ -931,14 +931,15 @@ __device__ __forceinline__ void ns_idct_taps(float melOut, BackLds &B, const NsC
  * of 25 dependent additions): the producer adds terms 0 .. K-1 and hands over the partial sums of rows 0..8 and the
  * remaining gains; the consumer continues with terms K .. 24 in the same order, then windows and mirrors the taps.
  * rec layout: [0..24] mel gains (only K.. are read), [28..36] partial sums of rows 0..8. */
+/* bregs (optional): the lane's basis column in registers (bregs[f] = basis[f][min(lane, 8)]) instead of 25 LDS reads per frame */
 template <int K>
-__device__ __forceinline__ void ns_idct_head(float melOut, float *rec, int lane, const float *idctLds)
+__device__ __forceinline__ void ns_idct_head(float melOut, float *rec, int lane, const float *idctLds, const float *bregs = nullptr)
 {
     float h = 0.0f;
     const int l = (lane <= 8) ? lane : 8;
 #pragma unroll
     for (int f = 0; f < K; ++f)
-        h += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(melOut), f)) * idctLds[f * 16 + l];
+        h += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(melOut), f)) * (bregs ? bregs[f] : idctLds[f * 16 + l]);
     if (lane <= 8) rec[28 + lane] = h;
     if (lane >= K && lane < SEA_NMEL) rec[lane] = melOut;
     wave_sync();
@@ -1063,6 +1064,78 @@ __device__ __forceinline__ float ns_fir_dif(const float *fir, const float *buf, 
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y1), 39));
 }
 
+/* ---- the same taps and filter without their trips through LDS (round 4; the latency-bound four-wave form) ----------
+ * An LDS round trip (store, fence, broadcast reads) costs a role ~200 clk of its chain.  The nine distinct taps sit one per
+ * lane (lane k: tap[8 - k] = tap[8 + k]) and reach the multiplies as scalar operands through v_readlane; the filter's two
+ * outputs per lane stay in registers for whoever consumes them.  Same operations in the same order. */
+struct FirTaps {
+    float t[9];
+};
+__device__ __forceinline__ FirTaps fir_taps_rl(float tap)
+{
+    FirTaps T;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) T.t[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tap), k));
+    return T;
+}
+/* ApplyWF (NoiseSup.c:324-340) as ns_fir_apply computes it: lanes 0..39 get outputs 2l and 2l + 1 (lanes >= 40 repeat lane 39) */
+__device__ __forceinline__ void ns_fir_regs(const FirTaps &T, const float *buf, int lane, float &y0, float &y1)
+{
+    float x[18];
+    const int l = (lane < 40) ? lane : 39;
+    const float *src = buf + 72 + 2 * l; /* x[m] = buf[72 + 2l + m] */
+#pragma unroll
+    for (int m = 0; m < 18; m += 2) {
+        const float2 v = *reinterpret_cast<const float2 *>(src + m);
+        x[m] = v.x;
+        x[m + 1] = v.y;
+    }
+    y0 = 0.0f, y1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SEA_NTAP; ++k) {
+        const float c = T.t[k < 8 ? 8 - k : k - 8];
+        y0 += c * x[16 - k];
+        y1 += c * x[17 - k];
+    }
+}
+/* DoMelIDCT rows 0..8 + Hanning(17) as ns_idct_taps<.., RL = true> computes them, the tap left in lane k (k = 0..8) */
+__device__ __forceinline__ float ns_idct_tap_rl(float melOut, float irWin, int lane, const float *idctLds, const float *bregs = nullptr)
+{
+    const int l = (lane <= 8) ? lane : 8;
+    float h = 0.0f;
+#pragma unroll
+    for (int f = 0; f < SEA_NMEL; ++f)
+        h += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(melOut), f)) * (bregs ? bregs[f] : idctLds[f * 16 + l]);
+    return h * irWin;
+}
+/* ns_idct_tail with the tap left in lane k instead of the 17 taps in LDS */
+template <int K>
+__device__ __forceinline__ float ns_idct_tail_rl(const float *rec, const float *idctLds, float irWin, int lane)
+{
+    const int l = (lane <= 8) ? lane : 8;
+    float m[SEA_NMEL], b[SEA_NMEL];
+#pragma unroll
+    for (int f = K; f < SEA_NMEL; ++f) {
+        m[f] = rec[f];
+        b[f] = idctLds[f * 16 + l];
+    }
+    float h = rec[28 + l];
+#pragma unroll
+    for (int f = K; f < SEA_NMEL; ++f) h += m[f] * b[f];
+    return h * irWin;
+}
+/* ns_fir_dif on register taps */
+__device__ __forceinline__ float ns_fir_dif_rl(const FirTaps &T, const float *buf, int lane, float lastIn, float &d0, float &d1)
+{
+    float y0, y1;
+    ns_fir_regs(T, buf, lane, y0, y1);
+    const float below = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lastIn), __float_as_int(y1), 0x138 /* wave_shr:1 */,
+                                                                   0xf, 0xf, false));
+    d0 = y0 - below;
+    d1 = y1 - y0;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y1), 39));
+}
+
 template <bool LDSBASIS, bool RL = false>
 __device__ __forceinline__ void ns_idct_fir(float melOut, BackLds &B, const NsConst &C, const float *buf,
                                             float *dst, int lane, const float *idctLds)
@@ -1129,7 +1202,10 @@ template <int ST, bool PIPE, bool FD = false, bool DEFER_FIR = false, bool RL = 
 __device__ __forceinline__ void ns_back(const float *psd, const float *buf, BackLds &B, NsRegs &s,
                                         const NsConst &C, float *dst, int lane, float frameEnExt = 0.0f,
                                         float *spectOut = nullptr, const float *idctLds = nullptr,
-                                        NsFd *fd = nullptr, int *fdFlags = nullptr, float *fdRec = nullptr)
+                                        NsFd *fd = nullptr, int *fdFlags = nullptr, float *fdRec = nullptr,
+                                        float *yRegs = nullptr /* RL, !DEFER_FIR: the filter's two outputs of this lane stay in
+                                                                * yRegs[0..1] (ns_fir_regs), dst is not written */,
+                                        const float *bregs = nullptr /* RL: the IDCT basis column in registers (ns_idct_head) */)
 {
     NS_BACK_CK_START;
     const float nSigLo = psd[lane], nSigHi = psd[64];
@@ -1196,7 +1272,7 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
             float melOut = ns_mel_fb(B, C, lane);
             melOut = (float)((double)(s.alfaGF * melOut) + (1.0 - (double)s.alfaGF) * 1.0);
             if (IDCT_HEAD >= 0)
-                ns_idct_head<(IDCT_HEAD >= 0 ? IDCT_HEAD : 0)>(melOut, dst, lane, idctLds);
+                ns_idct_head<(IDCT_HEAD >= 0 ? IDCT_HEAD : 0)>(melOut, dst, lane, idctLds, bregs);
             else
                 ns_idct_taps<PIPE, RL>(melOut, B, C, lane, idctLds, dst); /* the 17 taps straight into the consumer's record */
             return;
@@ -1274,11 +1350,13 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
     }
     NS_BACK_CK(3); /* in-order sum, gain factor */
     if (DEFER_FIR && IDCT_HEAD >= 0) {
-        ns_idct_head<(IDCT_HEAD >= 0 ? IDCT_HEAD : 0)>(melOut, dst, lane, idctLds);
+        ns_idct_head<(IDCT_HEAD >= 0 ? IDCT_HEAD : 0)>(melOut, dst, lane, idctLds, bregs);
     } else if (DEFER_FIR) { /* the consumer wave applies the filter (ns_fir_apply): hand over the 17 taps */
         ns_idct_taps<PIPE, RL>(melOut, B, C, lane, idctLds);
         if (lane < SEA_NTAP) dst[lane] = B.fir[lane];
         wave_sync();
+    } else if (RL && PIPE && yRegs) {
+        ns_fir_regs(fir_taps_rl(ns_idct_tap_rl(melOut, C.irWin, lane, idctLds, bregs)), buf, lane, yRegs[0], yRegs[1]);
     } else {
         ns_idct_fir<PIPE, RL>(melOut, B, C, buf, dst, lane, idctLds);
     }
@@ -1579,6 +1657,30 @@ __device__ __forceinline__ bool dc_verify(const float *dif, float *out, float y0
     }
     wave_sync();
     return redo;
+}
+
+/* dc_verify with the output frame handed back in registers: lane l < 40 checks samples 2l and 2l + 1 and returns them
+ * (what the int16 cast and the store want next), all its operands fetched in one batch of LDS reads -- the check and
+ * the store used to be two round trips.  Lanes >= 40 repeat lane 39. */
+__device__ __forceinline__ float2 dc_verify_take(const float *dif, float *out, float y0, float &y, int lane)
+{
+    const int l = (lane < 40) ? lane : 39;
+    const float2 d = *reinterpret_cast<const float2 *>(dif + 2 * l);
+    float2 v = *reinterpret_cast<const float2 *>(out + 2 * l);
+    const float below = out[(l > 0) ? 2 * l - 1 : 0];
+    const bool unsafe = !(dc_step_ok(d.x, (l == 0) ? y0 : below) && dc_step_ok(d.y, v.x));
+    if (__ballot(unsafe) != 0ull) {
+        wave_sync();
+        y = y0;
+        for (int n = 0; n < SEA_HOP; ++n) {
+            y = (float)__fma_rn(0.9990234375, (double)y, (double)dif[n]);
+            out[n] = y;
+        }
+        wave_sync();
+        v = *reinterpret_cast<const float2 *>(out + 2 * l);
+    }
+    wave_sync();
+    return v;
 }
 
 /* DoNoiseSup (NoiseSup.c:1061-1440) for one 80-sample frame.  Lanes 0..39 pass samples 2l and

@@ -60,7 +60,7 @@ constexpr int kPipeWaves = 4;
 /* > 0: the same split with the TAIL in the helper wave S, which applies the taps anyway one beat after B1 (no extra
  * beat, no extra record): B1 adds the first 25 - SEA_IDCT_TAIL_S terms, S the last SEA_IDCT_TAIL_S, windows and mirrors */
 #ifndef SEA_IDCT_TAIL_S
-#define SEA_IDCT_TAIL_S 4 /* measured on configs[1], alternating A/B (tools/ns_ab.sh): 0: 2.19-2.24 ms, 4: 2.14-2.19, 7: 2.16-2.19, 10: 2.17-2.18 */
+#define SEA_IDCT_TAIL_S 8 /* round 4 (LDS-free taps, LRPT priorities): 4: 2.14 ms, 8: 2.11, 12: 2.11, 16: 2.13; round 3, measured on configs[1], alternating A/B (tools/ns_ab.sh): 0: 2.19-2.24 ms, 4: 2.14-2.19, 7: 2.16-2.19, 10: 2.17-2.18 */
 #endif
 /* 1 (experiment, off): the int16 cast and the output store (ParmInterface.c:266) of a frame run in the transform wave F one
  * beat after the helper wave finished it (F has ~900 clk of slack per frame, S none): double-buffered output frame in
@@ -74,6 +74,39 @@ constexpr bool kIdctSplit = (SEA_IDCT_IN_F || SEA_IDCT_TAIL_S > 0) && SEA_FIR_IN
 constexpr int kIdctHead = SEA_IDCT_IN_F ? SEA_IDCT_SPLIT : 25 - SEA_IDCT_TAIL_S;
 constexpr int kLagS = (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? 5 : 4; /* beats between a frame's intake and its output store */
 constexpr int kRec34 = (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? 4 : 2;    /* with the split: B1 writes at beat i, F at i + 1, S reads at i + 2 */
+/* 1 (four-wave forms with the address tables in VGPRs): the filter taps reach the 17-tap filters as scalar operands through
+ * v_readlane and the filters' outputs stay in registers (B0: straight into the stage-1 buffer; S: straight into the DC filter's
+ * differences), the helper wave fetches the operands of its exactness check and of the output store in one batch -- two LDS
+ * round trips (~200 clk each) less on B0's chain, two less on S's */
+#ifndef SEA_TAPS_RL
+#define SEA_TAPS_RL 1
+#endif
+/* 1 (four-wave forms with the address tables in VGPRs): the two BACK waves keep their column of the 9 x 25 IDCT basis in
+ * registers (the kernel's register budget is set by the transform wave's address tables, these roles have room) instead
+ * of 25 + 21 LDS reads of constants per frame */
+#ifndef SEA_BASIS_REGS
+#define SEA_BASIS_REGS 1
+#endif
+/* 1: issue priority by REMAINING frames instead of by launch row (longest-remaining-processing-time first, the makespan
+ * rule): a workgroup's waves run at s_setprio 3 while more than 3/4 of the batch's longest utterance is still ahead of
+ * them, 2 above 1/2, 1 above 1/4, 0 below -- re-evaluated every SEA_PRIO_STEP frames -- so the utterances of a CU converge
+ * on a common finishing time whatever their lengths.  (The static rows gave the longest utterance of a CU its lone frame
+ * period from start to end and starved the third row: rows 0/1 finished at 2.09 / 2.15 ms, row 2 at 2.39, tools/ns_finish_order.py.) */
+#ifndef SEA_PRIO_LRPT
+#define SEA_PRIO_LRPT 1
+#endif
+#ifndef SEA_PRIO_STEP
+#define SEA_PRIO_STEP 16
+#endif
+#ifndef SEA_PRIO_LEVELS
+#define SEA_PRIO_LEVELS 32 /* 4: plain quarters; 16: sixteenths, dithered over four steps */
+#endif
+#ifndef SEA_PRIO_ROWBIAS
+#define SEA_PRIO_ROWBIAS 1
+#endif
+#ifndef SEA_PRIO_DITHER
+#define SEA_PRIO_DITHER 1
+#endif
 /* waves per SIMD the register allocation must leave room for (= workgroups per CU of this 4-wave kernel) */
 #ifndef SEA_NS_MIN_WAVES
 #define SEA_NS_MIN_WAVES 4
@@ -134,7 +167,8 @@ struct RoleTimer {
 #define NS_T_FLUSH(slot)
 #endif
 
-struct __attribute__((aligned(16))) Rec01 { /* F -> B0, S */
+/* F -> B0, S (r01) and F -> B1 (r23) */
+struct __attribute__((aligned(16))) RecPsd {
     float psd[68];
     int valid, tick, pad0, pad1;
 };
@@ -145,10 +179,6 @@ struct __attribute__((aligned(16))) Rec12 { /* B0 -> F, S */
 struct __attribute__((aligned(16))) RecFd { /* S -> F, same variant: the measures' three sums of the frame S summed at this beat */
     float mean, var, tempEn, m1, m2, m3;
     int nb16, vadns, tick, pad0, pad1, pad2; /* tick 0: the first stage did not run */
-};
-struct __attribute__((aligned(16))) Rec23 { /* F -> B1 */
-    float psd[68];
-    int valid, tick, pad0, pad1;
 };
 struct __attribute__((aligned(16))) Rec34 { /* B1 -> F -> S */
     float mel[kIdctSplit ? 40 : 4]; /* split IDCT: [k..24] second-stage mel gains (gain factor applied) whose IDCT terms F still has to
@@ -172,9 +202,9 @@ struct __attribute__((aligned(16))) PipeLds {
     float denSum[kSlots];           /* sum of denSigSE1 of tick t at [t & 7] */
     int fdFlags[kSlots];            /* speech flags of tick t at [t & 7] (frame-dropping VAD variant) */
     float idctT[SEA_NMEL * 16];     /* mel-IDCT basis rows 0..8: [f][16], shared by B0 and B1 */
-    Rec01 r01[2];
+    RecPsd r01[2];
     Rec12 r12[2];
-    Rec23 r23[2];
+    RecPsd r23[2];
     Rec34 r34[kRec34];
     /* frame-dropping VAD variant only, BEHIND everything else (the other forms keep their layout): what B0 leaves of frame f
      * (by parity) for the speech measures (ns_core.h, kFdRecFloats), and their sums on the way from S to F */
@@ -208,8 +238,13 @@ __device__ __forceinline__ void block_sync()
 
 /* constants a BACK wave keeps in registers (each wave loads only its own: the role branches below
  * have separate loops so that register allocation is per role) */
+template <bool BASIS = false>
 __device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables *t, int lane)
 {
+    if (BASIS) {
+#pragma unroll
+        for (int f = 0; f < SEA_NMEL; ++f) C.idct[f] = t->idct[f][lane <= 8 ? lane : 8];
+    }
     C.melStart = t->melStart[lane];
     C.melLen = t->melLen[lane];
 #pragma unroll
@@ -227,7 +262,9 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
     /* Issue priority by launch row: the launch order puts the longest utterances first, in rows of one workgroup per
      * CU, and the step ends when the longest utterance does -- its waves (row 0) get s_setprio 3, row 1 -> 2, row 2 -> 1
      * (measured on the bench corpus, alternating A/B on one box: -2 %).  prio_row = 0 switches it off. */
-    if (a.prio_row > 0) {
+    constexpr bool kLrptForm = SEA_PRIO_LRPT && !ADDR_LDS && !SLICES; /* whole utterances in the four-wave form */
+    const bool lrpt = kLrptForm && a.prio_row > 0 && a.order && !a.state;
+    if (a.prio_row > 0 && !lrpt) {
         const int row = a.prio_base + (int)blockIdx.x / a.prio_row;
         if (row == 0) __builtin_amdgcn_s_setprio(3);
         else if (row == 1) __builtin_amdgcn_s_setprio(2);
@@ -235,6 +272,22 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
     }
     const long long off = a.offsets[u];
     const long long nfr = a.lengths[u] / SEA_HOP;
+    /* LRPT: sixteenths of the longest utterance of the batch (block 0's: the launch order is longest first), dithered over
+     * four consecutive steps into the four hardware levels: average priority (L + 1.5) / 4 for L = 16 rem / longest */
+    const long long longestFr = lrpt ? a.lengths[a.order[0]] / SEA_HOP : 0;
+    const float lrptScale = (float)SEA_PRIO_LEVELS / (float)(longestFr > 0 ? longestFr : 1);
+    const int lrptBias = lrpt ? SEA_PRIO_ROWBIAS * ((int)blockIdx.x / a.prio_row) : 0; /* equal levels: the hardware prefers the oldest wave */
+    auto prio_by_remaining = [&](long long i) {
+        if (kLrptForm && lrpt && (i & (SEA_PRIO_STEP - 1)) == 0) {
+            const int L = __builtin_amdgcn_readfirstlane((int)((float)(nfr - i) * lrptScale)) + lrptBias;
+            const int d = SEA_PRIO_DITHER ? (int)((i / SEA_PRIO_STEP) & (SEA_PRIO_LEVELS / 4 - 1)) : 0;
+            const int pr = (L + d) / (SEA_PRIO_LEVELS / 4);
+            if (pr >= 3) __builtin_amdgcn_s_setprio(3);
+            else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+    };
     const long long niter = nfr + kLagS + (SEA_STORE_IN_F ? 1 : 0);
 
     /* time slices (NsBatchArgs::state): the recursion of utterance u between two launches */
@@ -321,6 +374,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
         float *outfF = a.out_f32 ? a.out_f32 + off : nullptr;
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
+            prio_by_remaining(i);
             NS_T_CK_START;
             if (SEA_STORE_IN_F) { /* cast + store of the frame the helper wave finished one beat ago */
                 const long long fs = i - kLagS - 1;
@@ -341,7 +395,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
             }
             /* stage 0, frame i */
             bool actA = false;
-            Rec01 &rA = L.r01[i & 1];
+            auto &rA = L.r01[i & 1];
             if (i < nfr) {
                 /* nbFramesInFirstStage - nbFramesInSecondStage > 2 (NoiseSup.c:1152) <=> tick >= 3 */
                 actA = (SEA_ROLE_MASK & 1) && vCur && tCur >= 3;
@@ -354,7 +408,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
             const long long fB = i - 2;
             bool actB = false;
             const int tA = tCur, tB = t2;
-            Rec23 &rB = L.r23[fB & 1];
+            auto &rB = L.r23[fB & 1];
             if (fB >= 0 && fB < nfr) {
                 actB = (SEA_ROLE_MASK & 1) && v2 && tB >= 5;
                 if (lane == 0) {
@@ -417,7 +471,8 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
     } else if (role == 1) {
         /* ---- B0: BACK of stage 0; its 80 outputs enter the stage-1 buffer ---- */
         NsConst C;
-        load_back_const(C, a.tables, lane);
+        constexpr bool kBregs = SEA_BASIS_REGS && !ADDR_LDS && SEA_TAPS_RL;
+        load_back_const<kBregs>(C, a.tables, lane);
         NsRegs s;
         regs_init(s, C.eps);
         NsFd fd;
@@ -431,9 +486,10 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
         }
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
+            prio_by_remaining(i);
             const long long f = i - 1;
             if (f >= 0 && f < nfr) {
-                const Rec01 &r = L.r01[f & 1];
+                const auto &r = L.r01[f & 1];
                 Rec12 &o = L.r12[f & 1];
                 const int valid = r.valid, t = r.tick;
                 if ((SEA_ROLE_MASK & 2) && valid && t >= 3) {
@@ -443,12 +499,18 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                      * here, by its consumer: this wave has ~1000 clk of slack per frame, the helper wave none */
                     /* FD: the speech measures' inputs go into o.fd; S sums them in free lanes of its chain one beat later, F
                      * runs their scalar logic the beat after (this wave has no slack left for ~1300 clk of them) */
+                    constexpr bool kRegs = SEA_TAPS_RL && !ADDR_LDS;
+                    float y01[2] = {0.0f, 0.0f};
                     ns_back<0, true, FD, false, !ADDR_LDS>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
                                          vad_frame_energy(L.frameEn[t & (kSlots - 1)]), o.den, L.idctT, &fd, &bits,
-                                         FD ? L.fdRec[f & 1] : nullptr);
+                                         FD ? L.fdRec[f & 1] : nullptr, kRegs ? y01 : nullptr, kBregs ? C.idct : nullptr);
                     if (lane < 40) {
-                        const float2 v = *reinterpret_cast<const float2 *>(tmp + 2 * lane);
-                        slot_store(L.circ[1], t, lane, v.x, v.y);
+                        if (kRegs) {
+                            slot_store(L.circ[1], t, lane, y01[0], y01[1]);
+                        } else {
+                            const float2 v = *reinterpret_cast<const float2 *>(tmp + 2 * lane);
+                            slot_store(L.circ[1], t, lane, v.x, v.y);
+                        }
                     }
                 }
                 if (lane == 0) {
@@ -473,7 +535,8 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
     } else if (role == 2) {
         /* ---- B1: BACK of stage 1 ---- */
         NsConst C;
-        load_back_const(C, a.tables, lane);
+        constexpr bool kBregs = SEA_BASIS_REGS && !ADDR_LDS && kIdctSplit;
+        load_back_const<kBregs>(C, a.tables, lane);
         NsRegs s;
         regs_init(s, C.eps);
         if (resume) {
@@ -484,9 +547,10 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
         }
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
+            prio_by_remaining(i);
             const long long f = i - 3;
             if (f >= 0 && f < nfr) {
-                const Rec23 &r = L.r23[f & 1];
+                const auto &r = L.r23[f & 1];
                 Rec34 &o = L.r34[f & (kRec34 - 1)];
                 const int valid = r.valid, t = r.tick;
                 int produced = 0;
@@ -497,7 +561,8 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                     s.denEn2 = L.denSum[t & (kSlots - 1)];
                     ns_back<1, true, false, SEA_FIR_IN_S != 0, !ADDR_LDS, kIdctSplit ? kIdctHead : -1>(
                         r.psd, L.circ[1] + window_base(t), L.back[1], s, C,
-                        SEA_FIR_IN_S ? (kIdctSplit ? o.mel : o.fir) : o.out, lane, 0.0f, nullptr, L.idctT);
+                        SEA_FIR_IN_S ? (kIdctSplit ? o.mel : o.fir) : o.out, lane, 0.0f, nullptr, L.idctT, nullptr, nullptr, nullptr,
+                        nullptr, kBregs ? C.idct : nullptr);
                     produced = 1;
                 }
                 if (lane == 0) {
@@ -528,6 +593,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
         NS_T_CK_DECL;
         for (long long i = 0; i < niter; ++i) {
             NS_T_BEGIN;
+            prio_by_remaining(i);
             NS_T_CK_START;
             /* (1) VAD log-energy (NoiseSup.c:386-391) of the frame pushed at i-1 = tick tp; it is
              *     the "current frame" buf[80..159] of tick tp+2
@@ -543,7 +609,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
             const float *fdSrc = L.fdRec[0];
             float fdSums[3] = {0.0f, 0.0f, 0.0f};
             if (fp >= 0 && fp < nfr) {
-                const Rec01 &r = L.r01[fp & 1];
+                const auto &r = L.r01[fp & 1];
                 doVad = (SEA_ROLE_MASK & 16) && r.valid;
                 tp = r.tick;
             }
@@ -556,6 +622,8 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
             }
             const bool haveOut = fo >= 0 && fo < nfr;
             float *soutS = L.sout[SEA_STORE_IN_F ? (fo & 1) : 0];
+            constexpr bool kTake = SEA_TAPS_RL && !ADDR_LDS && !SEA_STORE_IN_F; /* dc_verify_take: check + output in one batch */
+            float2 vOut = make_float2(0.0f, 0.0f);
             if (haveOut) produced = (SEA_ROLE_MASK & 64) && L.r34[fo & (kRec34 - 1)].produced != 0;
             /* everything the chains need goes into LDS in one batch: the squares of the VAD frame and the DC filter's
              * input differences, straight from the second-stage FIR's registers (stage-1 17-tap FIR, NoiseSup.c:324-340) */
@@ -568,10 +636,14 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                 }
                 if (produced) {
                     Rec34 &r = L.r34[fo & (kRec34 - 1)];
-                    if (SEA_IDCT_TAIL_S > 0 && !SEA_IDCT_IN_F && SEA_FIR_IN_S) /* finish the taps B1 started */
+                    constexpr bool kTapsRl = SEA_TAPS_RL && !ADDR_LDS && SEA_IDCT_TAIL_S > 0 && !SEA_IDCT_IN_F && SEA_FIR_IN_S;
+                    if (!kTapsRl && SEA_IDCT_TAIL_S > 0 && !SEA_IDCT_IN_F && SEA_FIR_IN_S) /* finish the taps B1 started */
                         ns_idct_tail<kIdctHead>(r.mel, L.idctT, irWinS, r.fir, lane);
                     if (SEA_ABL_S & 1) {
                         d0 = d1 = dcX;
+                    } else if (kTapsRl) { /* the taps B1 started, finished in lanes 0..8 and read as scalars; no trip through LDS */
+                        dcX = ns_fir_dif_rl(fir_taps_rl(ns_idct_tail_rl<kIdctHead>(r.mel, L.idctT, irWinS, lane)),
+                                            L.circ[1] + window_base(r.tick), lane, dcX, d0, d1);
                     } else if (SEA_FIR_IN_S) {
                         dcX = ns_fir_dif(r.fir, L.circ[1] + window_base(r.tick), lane, dcX, d0, d1);
                     } else {
@@ -617,7 +689,8 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                 if (produced) {
                     /* (checking the recurrence's exactness condition on the sixteen recomputing lanes' registers instead
                      * was measured slower: five checks in a row per lane against two per lane here) */
-                    dc_verify(L.sdif, soutS, dcY, y, lane);
+                    if (kTake) vOut = dc_verify_take(L.sdif, soutS, dcY, y, lane);
+                    else dc_verify(L.sdif, soutS, dcY, y, lane);
                     dcY = y;
                     if (firstOut < 0) firstOut = (int)fo + (blob ? a.frame_base : 0);
                 }
@@ -633,7 +706,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                 if (ln < 40 && !(SEA_ABL_S & 4)) {
                     uint32_t packed = 0u;
                     if (produced) {
-                        const float2 v = *reinterpret_cast<const float2 *>(&soutS[2 * ln]);
+                        const float2 v = kTake ? vOut : *reinterpret_cast<const float2 *>(&soutS[2 * ln]);
                         packed = (uint32_t)cast_i16(v.x) | ((uint32_t)cast_i16(v.y) << 16);
                         if (outf) *reinterpret_cast<float2 *>(outf + fo * SEA_HOP + 2 * ln) = v;
                     }
