@@ -135,6 +135,34 @@ __device__ __forceinline__ void tile_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+/* Issue priority by REMAINING tiles (longest-remaining-processing-time first, as the four-wave NoiseSup kernel has it,
+ * ns_pipe_kernel.hip: SEA_PRIO_LRPT): every wave counts its tile barriers down and, every 64 tiles, sets s_setprio from
+ * 32 * remaining / (the batch's longest utterance) dithered over eight consecutive evaluations into the four hardware
+ * levels, so that the utterances sharing a CU converge on a common finishing time.  scale = 0: off. */
+#ifndef SEA_RS_LRPT
+#define SEA_RS_LRPT 1
+#endif
+struct TilePrio {
+    long long left; /* tile barriers this wave still has to pass */
+    float scale;    /* 32 / (tile barriers of the batch's longest utterance); 0: off */
+    __device__ __forceinline__ void tick()
+    {
+        --left;
+        if (SEA_RS_LRPT && scale > 0.0f && (left & 63) == 0) {
+            const int lv = __builtin_amdgcn_readfirstlane((int)((float)left * scale)) + (int)((left >> 6) & 7);
+            if (lv >= 24) __builtin_amdgcn_s_setprio(3);
+            else if (lv >= 16) __builtin_amdgcn_s_setprio(2);
+            else if (lv >= 8) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+    }
+};
+__device__ __forceinline__ void tile_sync(TilePrio &p)
+{
+    tile_sync();
+    p.tick();
+}
+
 constexpr int kTile = 16;        /* time steps per hand-over between the pipelined waves */
 constexpr int kMacro = 2;        /* tiles per HBM request group of the synthesis pass */
 constexpr int kTileStride = 68;  /* floats per step in the padded tile: 64 channels + 4 (rows stay 16-byte aligned
@@ -290,7 +318,7 @@ struct __attribute__((aligned(16))) FwdLds {
 
 /* roles 0..2 work; any further wave of the workgroup only keeps the barrier count (fused kernel) */
 __device__ __forceinline__ void resynth_fwd_body(const ResynthArgs &a, FwdLds &S, int role, int lane, int u,
-                                                 long long off, long long L)
+                                                 long long off, long long L, TilePrio &tp)
 {
     v2f(*pq)[kTile][64] = S.pq;
     v2f(*pa)[kTile][64] = S.pa;
@@ -298,7 +326,7 @@ __device__ __forceinline__ void resynth_fwd_body(const ResynthArgs &a, FwdLds &S
     const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 2;
     RS_T_DECL;
     if (role > 2) {
-        for (long long j = 0; j < niter; ++j) tile_sync();
+        for (long long j = 0; j < niter; ++j) tile_sync(tp);
     } else if (role == 0) {
         const int16_t *in = a.in + off;
         const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
@@ -320,7 +348,7 @@ __device__ __forceinline__ void resynth_fwd_body(const ResynthArgs &a, FwdLds &S
                 wave_sync();
             }
             RS_T_MID;
-            tile_sync();
+            tile_sync(tp);
             RS_T_END;
         }
         RS_T_FLUSH(0);
@@ -337,7 +365,7 @@ __device__ __forceinline__ void resynth_fwd_body(const ResynthArgs &a, FwdLds &S
                 for (int t = 0; t < kTile; ++t) o[t][lane] = gt_step_mid(s, i[t][lane], C);
             }
             RS_T_MID;
-            tile_sync();
+            tile_sync(tp);
             RS_T_END;
         }
         RS_T_FLUSH(2);
@@ -366,7 +394,7 @@ __device__ __forceinline__ void resynth_fwd_body(const ResynthArgs &a, FwdLds &S
                     *reinterpret_cast<float4 *>(row + k * 256) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
             }
             RS_T_MID;
-            tile_sync();
+            tile_sync(tp);
             RS_T_END;
         }
         RS_T_FLUSH(4);
@@ -381,7 +409,8 @@ __global__ __launch_bounds__(192, 3) void resynth_fwd_kernel(ResynthArgs a)
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    resynth_fwd_body(a, S, role, lane, u, a.offsets[u], a.lengths[u]);
+    TilePrio tp = {0, 0.0f};
+    resynth_fwd_body(a, S, role, lane, u, a.offsets[u], a.lengths[u], tp);
 }
 
 /* gammaToneFilter() for one channel of the bank (HuWang.h:49): a serial recurrence, one lane. */
@@ -420,7 +449,7 @@ struct __attribute__((aligned(16))) BwdLds {
 
 /* four waves; the caller has excluded L < 320 (no mask frame fits) */
 __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S, int role, int lane, int u,
-                                                 long long off, long long L)
+                                                 long long off, long long L, TilePrio &tp)
 {
     v2f(*pq)[kTile][64] = S.pq;
     float(*gp)[kTile * kTileStride] = S.gp;
@@ -438,7 +467,7 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
         S.wbin[2][i] = (float)((double)0.0f + up * 1.0);
         S.wbin[3][i] = (float)((double)wd + up * 1.0);
     }
-    tile_sync();
+    tile_sync(tp);
 
     RS_T_DECL;
     if (role == 0) {
@@ -494,7 +523,7 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
                     }
                 }
                 RS_T_MID;
-                tile_sync();
+                tile_sync(tp);
                 RS_T_END;
             }
 #pragma unroll
@@ -517,7 +546,7 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
                 for (int t = 0; t < kTile; ++t) o[t * kTileStride] = gt_step_hi(s, i[t][lane], C, gain);
             }
             RS_T_MID;
-            tile_sync();
+            tile_sync(tp);
             RS_T_END;
         }
         RS_T_FLUSH(8);
@@ -600,7 +629,7 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
                 }
             }
             RS_T_MID;
-            tile_sync();
+            tile_sync(tp);
             RS_T_END;
         }
         RS_T_FLUSH(10);
@@ -637,7 +666,7 @@ __device__ __forceinline__ void resynth_bwd_body(const ResynthArgs &a, BwdLds &S
                 }
             }
             RS_T_MID;
-            tile_sync();
+            tile_sync(tp);
             RS_T_END;
         }
         RS_T_FLUSH(12);
@@ -654,7 +683,8 @@ __global__ __launch_bounds__(256, 4) void resynth_bwd_kernel(ResynthArgs a)
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long L = a.lengths[u];
     if (L < ((a.binary & 2) ? 160 : 320)) return; /* no mask frame fits (wave-uniform exit before any barrier) */
-    resynth_bwd_body(a, S, role, lane, u, a.offsets[u], L);
+    TilePrio tp = {0, 0.0f};
+    resynth_bwd_body(a, S, role, lane, u, a.offsets[u], L, tp);
 }
 
 /* Both passes of one utterance in ONE workgroup, back to back: the analysis pass of the long
@@ -672,14 +702,22 @@ __global__ __launch_bounds__(256, 4) void resynth_fused_kernel(ResynthArgs a)
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    /* (issue priority by launch row, as the NoiseSup kernel has it: measured 13.55 / 13.92 against 13.56 / 13.46 ms, no gain) */
+    /* (issue priority by launch ROW, as the NoiseSup kernel had it in round 3: 13.55 / 13.92 against 13.56 / 13.46 ms, no gain; by
+     * REMAINING tiles -- TilePrio, round 4 -- 13.36 against 13.60 ms (ratio masks), 12.74 against 13.05 (binary), alternating A/B) */
     const long long off = a.offsets[u], L = a.lengths[u];
     if (L < ((a.binary & 2) ? 160 : 320)) return; /* no mask frame fits */
-    resynth_fwd_body(a, S.f, role, lane, u, off, L);
+    /* both passes' tile barriers of this utterance against those of the batch's longest (block 0's: longest first) */
+    TilePrio tp = {0, 0.0f};
+    if (a.order && gridDim.x > 1) {
+        const long long Lmax = a.lengths[a.order[0]];
+        tp.left = 2 * ((L + kTile - 1) / kTile) + 7;
+        tp.scale = 32.0f / (float)(2 * ((Lmax + kTile - 1) / kTile) + 7);
+    }
+    resynth_fwd_body(a, S.f, role, lane, u, off, L, tp);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    resynth_bwd_body(a, S.b, role, lane, u, off, L);
+    resynth_bwd_body(a, S.b, role, lane, u, off, L, tp);
 }
 
 /* ---- subbband() -- the analysis half on its own --------------------------------
@@ -756,6 +794,8 @@ __global__ __launch_bounds__(384) void subband_kernel(SubbandArgs a)
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long off = a.offsets[u], L = a.lengths[u];
     const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 4;
+    /* (issue priority by remaining tiles, as the fused resynthesis kernel has it: 14.0-14.1 against 13.6-13.7 ms here -- six-wave
+     * workgroups, two per CU: off) */
     RS_T_DECL;
     if (role == 0) {
         const int16_t *in = a.in + off;

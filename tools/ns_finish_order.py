@@ -26,3 +26,10 @@ for b in idx: print(int(b), int(frames[b]), round(float(span[b])), round(float(e
 print("block 0..5:", [(int(frames[b]), round(float(span[b])), round(float(end[b]),1)) for b in range(6)])
 for lo, hi in ((0,256),(256,512),(512,768),(768,1024)):
     print("row", lo//256, "median ns/frame", round(float(np.median(span[lo:hi]))), "max end_us", round(float(end[lo:hi].max()),1))
+# spread of the finishing times over the CUs (workgroups b, b + 256, b + 512, b + 768 are launched onto one CU when the dispatcher
+# deals the first 256 out one per CU): the latest finisher of each such group
+grp = end.reshape(4, 256).max(axis=0)
+print("per launch column: latest end_us  min", round(float(grp.min()), 1), "median", round(float(np.median(grp)), 1), "max", round(float(grp.max()), 1))
+fr = frames.reshape(4, 256).sum(axis=0)
+print("frames per launch column: min", int(fr.min()), "max", int(fr.max()))
+hw = a[:, 1]
