@@ -40,6 +40,7 @@ namespace {
 /* timing-only diagnostic (-DSEA_RS_TIMING): per role, shader-clock cycles spent working and waiting
  * at the tile barrier, for workgroup 0 -> g_rs_timing[kernel*6 + role*2 + {0,1}] */
 #ifdef SEA_RS_TIMING
+__device__ unsigned g_rs_wg[4096 * 2]; /* fused kernel, per workgroup: start and end on the constant 100 MHz counter (low 32 bits) */
 __device__ unsigned long long g_rs_timing[32]; /* fwd R1,R2,R3 = 0..5; bwd R1,R2,W,SUM = 6..13; subband R1,R2,K,HC,W = 16..25 */
 struct RoleTimer {
     unsigned long long work = 0, wait = 0, t0 = 0, t1 = 0;
@@ -713,11 +714,17 @@ __global__ __launch_bounds__(256, 4) void resynth_fused_kernel(ResynthArgs a)
         tp.left = 2 * ((L + kTile - 1) / kTile) + 7;
         tp.scale = 32.0f / (float)(2 * ((Lmax + kTile - 1) / kTile) + 7);
     }
+#ifdef SEA_RS_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_rs_wg[2 * blockIdx.x] = (unsigned)wall_clock64();
+#endif
     resynth_fwd_body(a, S.f, role, lane, u, off, L, tp);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     resynth_bwd_body(a, S.b, role, lane, u, off, L, tp);
+#ifdef SEA_RS_TIMING
+    if (threadIdx.x == 192 && blockIdx.x < 4096) g_rs_wg[2 * blockIdx.x + 1] = (unsigned)wall_clock64(); /* the SUM wave ends last */
+#endif
 }
 
 /* ---- subbband() -- the analysis half on its own --------------------------------
@@ -934,6 +941,10 @@ __global__ __launch_bounds__(256) void selftest_div_kernel(const sea_gt_tables *
 } // namespace sea
 
 #ifdef SEA_RS_TIMING
+extern "C" int sea_debug_rs_wg(unsigned *out, int n_wg)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sea::g_rs_wg), (size_t)n_wg * 2 * sizeof(unsigned));
+}
 extern "C" int sea_debug_rs_timing(unsigned long long *out16)
 {
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(sea::g_rs_timing), 32 * sizeof(unsigned long long));

@@ -33,3 +33,10 @@ print("per launch column: latest end_us  min", round(float(grp.min()), 1), "medi
 fr = frames.reshape(4, 256).sum(axis=0)
 print("frames per launch column: min", int(fr.min()), "max", int(fr.max()))
 hw = a[:, 1]
+xcc = (a[:, 2] & 0xf).astype(np.int64)
+for x in range(8):
+    sel = xcc == x
+    if sel.any():
+        cols = np.unique(np.arange(n)[sel] % 256)
+        print("xcc", x, "workgroups", int(sel.sum()), "latest end_us median over its columns", round(float(np.median(grp[cols])), 1), "max", round(float(grp[cols].max()), 1),
+              "median ns/frame", round(float(np.median(span[sel]))))
