@@ -499,7 +499,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                      * here, by its consumer: this wave has ~1000 clk of slack per frame, the helper wave none */
                     /* FD: the speech measures' inputs go into o.fd; S sums them in free lanes of its chain one beat later, F
                      * runs their scalar logic the beat after (this wave has no slack left for ~1300 clk of them) */
-                    constexpr bool kRegs = SEA_TAPS_RL && !ADDR_LDS;
+                    constexpr bool kRegs = SEA_TAPS_RL && !ADDR_LDS; /* (the table-in-LDS form gains nothing from any of it: 464 M frames/s on the configs[4] shard either way) */
                     float y01[2] = {0.0f, 0.0f};
                     ns_back<0, true, FD, false, !ADDR_LDS>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
                                          vad_frame_energy(L.frameEn[t & (kSlots - 1)]), o.den, L.idctT, &fd, &bits,
