@@ -64,6 +64,9 @@ struct NsConst {
 #ifndef SEA_NS_FAST_DIV
 #define SEA_NS_FAST_DIV 1
 #endif
+#ifndef SEA_NOISE_SAFE
+#define SEA_NOISE_SAFE 1 /* skip the noise range test after a frame that ran inside the fast-division domain (ns_back) */
+#endif
 #ifndef SEA_NS_STEADY
 #define SEA_NS_STEADY 1 /* branch-free FilterCalc of (bin lane, bin 64) side by side in the forms without register pairs */
 #endif
@@ -82,6 +85,8 @@ struct NsRegs {
     int nIn1, nIn2, nOut2;
     int onset;
     int psdOk[2];                   /* previous frame's PSD was inside the fast-division domain (ns_psd_in_domain) */
+    int noiseSafe[2];               /* the previous frame ran inside the domain: its noise update cannot have left [2^-15, 2^28]
+                                     * (ns_back); 0 after DoNoiseSupInit and after any reload of the state: the range is then tested */
 };
 
 __device__ __forceinline__ void regs_init(NsRegs &s, float eps)
@@ -93,6 +98,7 @@ __device__ __forceinline__ void regs_init(NsRegs &s, float eps)
         s.prevLo[st] = s.prevHi[st] = 0.0f;
         s.nbFrame[st] = 0;
         s.psdOk[st] = 1; /* all-zero history is inside the domain */
+        s.noiseSafe[st] = 0;
     }
     s.dcX = s.dcY = 0.0f;
     s.denEn0 = s.denEn1 = s.denEn2 = 0.0f;
@@ -1236,9 +1242,15 @@ __device__ __forceinline__ void ns_back(const float *psd, const float *buf, Back
      * noise magnitude in [2^-15, 2^28] (>= eps = 2^-14.4 by construction; each update keeps it below
      * max(noise, 1.05 sqrt(P))).  Wave-uniform; always true for int16 audio ((200 * 32768)^2 = 2^45.3). */
     const bool psdOk = __ballot(!(ns_psd_in_domain(nSigLo) && ns_psd_in_domain(nSigHi))) == 0ull;
-    const bool noiseOk =
-        __ballot(!(s.noiseLo[ST] <= 0x1p28f && s.noiseHi[ST] <= 0x1p28f && s.noiseLo[ST] >= 0x1p-15f && s.noiseHi[ST] >= 0x1p-15f)) == 0ull;
+    /* The noise range is an invariant of the fast path: a frame inside the domain has P <= 2^48, and its update leaves the noise in
+     * [eps, max(noise, 1.05 sqrt(P))] (stage 0: a convex combination with sqrt(P), :531-546; stage 1: n2 * upd with upd <= 1 when
+     * n2 >= P and n2 * upd < 1.1 P otherwise, :492-508), so after a fast frame the test is skipped (~10 vector instructions per stage
+     * and frame); after anything else -- initial state, a reloaded state, a frame outside the domain -- it is made. */
+    bool noiseOk = true;
+    if (!SEA_NOISE_SAFE || !s.noiseSafe[ST])
+        noiseOk = __ballot(!(s.noiseLo[ST] <= 0x1p28f && s.noiseHi[ST] <= 0x1p28f && s.noiseLo[ST] >= 0x1p-15f && s.noiseHi[ST] >= 0x1p-15f)) == 0ull;
     const bool fast = SEA_NS_FAST_DIV && psdOk && noiseOk && (s.psdOk[ST] != 0);
+    s.noiseSafe[ST] = fast ? 1 : 0;
     s.psdOk[ST] = psdOk ? 1 : 0;
     float WLo, WHi;
     auto lane_sum = [&](float vLo, float vHi) { return ns_lane_sum65(vLo, vHi); };
