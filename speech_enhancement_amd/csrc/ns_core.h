@@ -1819,6 +1819,7 @@ __device__ __forceinline__ void state_load(const float *blob, NsLds &L, NsRegs &
     s.nbFrame[0] = qi[0]; s.nbFrame[1] = qi[1]; s.flagVAD = qi[2]; s.hangOver = qi[3];
     s.nbSpeech = qi[4]; s.nIn1 = qi[5]; s.nIn2 = qi[6]; s.nOut2 = qi[7]; s.onset = qi[8];
     s.psdOk[0] = qi[10] & 1; s.psdOk[1] = (qi[10] >> 1) & 1;
+    s.noiseSafe[0] = s.noiseSafe[1] = 0; /* a reloaded state: the noise range is tested on the first frame (ns_back) */
 }
 
 } // namespace
