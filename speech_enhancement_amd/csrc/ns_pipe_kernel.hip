@@ -116,6 +116,10 @@ constexpr int kRec34 = (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? 4 : 2;    /* with the s
 #endif
 /* timing-only ablations of the helper wave (results wrong by construction): 1 no second-stage FIR, 2 no VAD log,
  * 4 no output store, 8 no chains */
+/* timing-only ablation (results wrong by construction): the frame barrier on every second beat only */
+#ifndef SEA_ABL_HALFSYNC
+#define SEA_ABL_HALFSYNC 0
+#endif
 #ifndef SEA_ABL_S
 #define SEA_ABL_S 0
 #endif
@@ -447,7 +451,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
             vCur = 0;
             if (i + 1 < nfr) intake(i + 1);
             NS_T_MID;
-            block_sync();
+            if (!SEA_ABL_HALFSYNC || (i & 1)) block_sync();
             NS_T_END;
         }
         if (FD && a.onset_out && lane == 0) a.onset_out[u] = onset;
@@ -519,7 +523,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                 }
             }
             NS_T_MID;
-            block_sync();
+            if (!SEA_ABL_HALFSYNC || (i & 1)) block_sync();
             NS_T_END;
         }
         if (blob) {
@@ -571,7 +575,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
                 }
             }
             NS_T_MID;
-            block_sync();
+            if (!SEA_ABL_HALFSYNC || (i & 1)) block_sync();
             NS_T_END;
         }
         if (blob) {
@@ -718,7 +722,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
             }
             NS_T_CK(4);
             NS_T_MID;
-            block_sync();
+            if (!SEA_ABL_HALFSYNC || (i & 1)) block_sync();
             NS_T_END;
         }
         if (a.first_out && lane == 0) a.first_out[u] = firstOut;
