@@ -78,7 +78,9 @@ int sea_gammatone_channels(float *cf64, float *bw64, float *midEar64);
  * -------------------------------------------------------------------------------------------- */
 /* NoiseSup over a batch (etsi_denoise semantics per utterance).
  *   d_out_f32    optional: float NoiseSup output (pre-cast), same indexing as d_out
- *   d_order      optional: launch order (utterance indices, longest first balances the tail)
+ *   d_order      optional: launch order (utterance indices, longest first balances the tail; with more than one utterance per
+ *                CU the kernels also set their issue priority from the frames each utterance has left relative to the FIRST
+ *                utterance of this order, so that the utterances sharing a CU finish together -- results do not depend on it)
  *   d_first_out  optional: per utterance, frame index of the first output frame, -1 if none */
 int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
                          const long long *d_offsets, const long long *d_lengths, const int *d_order,
