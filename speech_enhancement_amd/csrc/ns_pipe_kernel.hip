@@ -88,10 +88,14 @@ constexpr int kRec34 = (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? 4 : 2;    /* with the s
 #define SEA_BASIS_REGS 1
 #endif
 /* 1: issue priority by REMAINING frames instead of by launch row (longest-remaining-processing-time first, the makespan
- * rule): a workgroup's waves run at s_setprio 3 while more than 3/4 of the batch's longest utterance is still ahead of
- * them, 2 above 1/2, 1 above 1/4, 0 below -- re-evaluated every SEA_PRIO_STEP frames -- so the utterances of a CU converge
- * on a common finishing time whatever their lengths.  (The static rows gave the longest utterance of a CU its lone frame
- * period from start to end and starved the third row: rows 0/1 finished at 2.09 / 2.15 ms, row 2 at 2.39, tools/ns_finish_order.py.) */
+ * rule).  Every SEA_PRIO_STEP frames each wave of a workgroup sets s_setprio from
+ *     L = SEA_PRIO_LEVELS * (frames its utterance has left) / (frames of the batch's longest utterance) + SEA_PRIO_ROWBIAS * launch row
+ * dithered over SEA_PRIO_LEVELS / 4 consecutive evaluations into the four hardware levels: level (L + d) / (LEVELS / 4) with
+ * d = 0 .. LEVELS / 4 - 1 in turn.  An utterance keeps the top level only while more of it is left than of its neighbours, so the
+ * utterances of a CU converge on a common finishing time whatever their lengths.  (The static rows gave the longest utterance of
+ * a CU its lone frame period from start to end and starved the third row: rows 0 / 1 finished at 2.09 / 2.15 ms, row 2 at 2.39,
+ * tools/ns_finish_order.py; 2.24 -> 2.15 ms per configs[1] step, profiles/r04_ns_priority_and_lone_period.txt.)  The launch row
+ * enters because among equal levels the hardware prefers the oldest wave.  Whole utterances in the four-wave form only. */
 #ifndef SEA_PRIO_LRPT
 #define SEA_PRIO_LRPT 1
 #endif
@@ -99,7 +103,7 @@ constexpr int kRec34 = (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? 4 : 2;    /* with the s
 #define SEA_PRIO_STEP 16
 #endif
 #ifndef SEA_PRIO_LEVELS
-#define SEA_PRIO_LEVELS 32 /* 4: plain quarters; 16: sixteenths, dithered over four steps */
+#define SEA_PRIO_LEVELS 32 /* 4 (no dither to speak of): 2.21 ms; 16: 2.17; 32: 2.15; 64 with step 8: 2.16 */
 #endif
 #ifndef SEA_PRIO_ROWBIAS
 #define SEA_PRIO_ROWBIAS 1
@@ -116,12 +120,13 @@ constexpr int kRec34 = (SEA_IDCT_IN_F && SEA_FIR_IN_S) ? 4 : 2;    /* with the s
 #endif
 /* timing-only ablations of the helper wave (results wrong by construction): 1 no second-stage FIR, 2 no VAD log,
  * 4 no output store, 8 no chains */
-/* timing-only ablation (results wrong by construction): the frame barrier on every second beat only */
-#ifndef SEA_ABL_HALFSYNC
-#define SEA_ABL_HALFSYNC 0
-#endif
 #ifndef SEA_ABL_S
 #define SEA_ABL_S 0
+#endif
+/* timing-only ablation (results wrong by construction): the frame barrier on every second beat only -- no gain on configs[1]
+ * or on the configs[4] shard: synchronising less often than once per frame is not what this pipeline lacks */
+#ifndef SEA_ABL_HALFSYNC
+#define SEA_ABL_HALFSYNC 0
 #endif
 
 
@@ -263,9 +268,9 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
-    /* Issue priority by launch row: the launch order puts the longest utterances first, in rows of one workgroup per
-     * CU, and the step ends when the longest utterance does -- its waves (row 0) get s_setprio 3, row 1 -> 2, row 2 -> 1
-     * (measured on the bench corpus, alternating A/B on one box: -2 %).  prio_row = 0 switches it off. */
+    /* Issue priority.  Whole utterances in the four-wave form: by remaining frames (SEA_PRIO_LRPT above, prio_by_remaining below).
+     * Otherwise (time slices, which hold the same frame range of every utterance) by launch row: the launch order puts the longest
+     * utterances first, in rows of one workgroup per CU; row 0 gets s_setprio 3, row 1 -> 2, row 2 -> 1.  prio_row = 0: off. */
     constexpr bool kLrptForm = SEA_PRIO_LRPT && !ADDR_LDS && !SLICES; /* whole utterances in the four-wave form */
     const bool lrpt = kLrptForm && a.prio_row > 0 && a.order && !a.state;
     if (a.prio_row > 0 && !lrpt) {
@@ -276,8 +281,7 @@ __device__ __forceinline__ void ns_pipe_body(const NsBatchArgs &a, PipeLds<ADDR_
     }
     const long long off = a.offsets[u];
     const long long nfr = a.lengths[u] / SEA_HOP;
-    /* LRPT: sixteenths of the longest utterance of the batch (block 0's: the launch order is longest first), dithered over
-     * four consecutive steps into the four hardware levels: average priority (L + 1.5) / 4 for L = 16 rem / longest */
+    /* the batch's longest utterance is block 0's (the launch order is longest first; any other order only makes the rule less sharp) */
     const long long longestFr = lrpt ? a.lengths[a.order[0]] / SEA_HOP : 0;
     const float lrptScale = (float)SEA_PRIO_LEVELS / (float)(longestFr > 0 ? longestFr : 1);
     const int lrptBias = lrpt ? SEA_PRIO_ROWBIAS * ((int)blockIdx.x / a.prio_row) : 0; /* equal levels: the hardware prefers the oldest wave */
