@@ -104,11 +104,14 @@ void gammatone_host_tables(float *cf64, float *bw64, float *midEar64)
     memcpy(midEar64, g_gt_host.midEar, sizeof g_gt_host.midEar);
 }
 
-/* Three forms of the same arithmetic (identical results), chosen by how many utterances share a CU:
+/* Forms of the same arithmetic (identical results), chosen by how many utterances share a CU:
  *   <= 2 per CU  six waves per utterance: shortest frame period (the run time is one utterance's
  *                chain of frames)                                     SEA_NS_KERNEL=pipe6
- *   <= 4 per CU  four waves, transform address tables in VGPRs       SEA_NS_KERNEL=pipe
+ *   <= 4 per CU  six waves per utterance compiled for seven waves per SIMD, so that four workgroups
+ *                co-reside on a CU (round 4; ns_pipe6_kernel.hip)     SEA_NS_KERNEL=pipe6d
  *   more         four waves, tables in LDS: six workgroups per CU     SEA_NS_KERNEL=big
+ *   (not chosen) four waves, transform address tables in VGPRs: the form for <= 4 per CU until round 4, 4 % behind the
+ *                dense six-wave form there; the time-slice launches of the host pipelines run on it   SEA_NS_KERNEL=pipe
  *   (never)      two utterances per workgroup, lane-sparse phases packed   SEA_NS_KERNEL=pair (experiment, slower)
  * SEA_NS_KERNEL=single: one wave per utterance (the streaming plug-in's kernel), for A/B. */
 int ns_pick_form(int n_inflight, int n_cu)
@@ -117,7 +120,7 @@ int ns_pick_form(int n_inflight, int n_cu)
     /* (form 5, two utterances per workgroup with their lane-sparse phases packed into one wave -- ns_pipe2_kernel.hip -- has
      * 22 % fewer vector instructions per frame and is slower: 434 against 465 M frames/s on the configs[4] shard; never
      * chosen here, see that file's header) */
-    return forced ? forced : (n_inflight <= 2 * n_cu ? 3 : (n_inflight <= 4 * n_cu ? 2 : 4));
+    return forced ? forced : (n_inflight <= 2 * n_cu ? 3 : (n_inflight <= 4 * n_cu ? 6 : 4));
 }
 
 int ns_launch(const sea::NsBatchArgs &a, int form, hipStream_t stream)
@@ -133,9 +136,13 @@ int ns_launch(const sea::NsBatchArgs &a, int form, hipStream_t stream)
     }
     if (form == 1)
         hipLaunchKernelGGL(sea::ns_denoise_kernel, dim3(a.n_utt), dim3(64), 0, stream, a);
-    else if (form == 3)
-        hipLaunchKernelGGL(sea::ns_denoise_pipe6_kernel, dim3(a.n_utt), dim3(384), 0, stream, a);
-    else if (form == 4)
+    else if (form == 3 || form == 6) {
+        sea::NsBatchArgs b = a;
+        static const int perm_env = [] { const char *e = getenv("SEA_NS6_PERM"); return e ? (int)strtol(e, nullptr, 8) : 0; }();
+        if (perm_env) b.perm6 = perm_env; /* diagnostic: the wave -> role map of the six-wave form, octal, wave 0 rightmost */
+        if (form == 6) hipLaunchKernelGGL(sea::ns_denoise_pipe6_dense_kernel, dim3(a.n_utt), dim3(384), 0, stream, b);
+        else hipLaunchKernelGGL(sea::ns_denoise_pipe6_kernel, dim3(a.n_utt), dim3(384), 0, stream, b);
+    } else if (form == 4)
         hipLaunchKernelGGL(sea::ns_denoise_pipe_big_kernel, dim3(a.n_utt), dim3(256), 0, stream, a);
     else if (form == 5)
         hipLaunchKernelGGL(sea::ns_denoise_pipe_pair_kernel, dim3((a.n_utt + 1) / 2), dim3(sea::ns_pair_threads()), 0, stream, a);
@@ -199,6 +206,7 @@ static int ns_form()
         if (e && !strcmp(e, "pipe6")) f = 3;
         if (e && !strcmp(e, "big")) f = 4;
         if (e && !strcmp(e, "pair")) f = 5;
+        if (e && !strcmp(e, "pipe6d")) f = 6;
         g_ns_form.store(f);
     }
     return f;
@@ -211,6 +219,7 @@ int sea_debug_ns_occupancy(int form)
     hipError_t e = hipErrorInvalidValue;
     if (form == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sea::ns_denoise_pipe_kernel, 256, 0);
     if (form == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sea::ns_denoise_pipe6_kernel, 384, 0);
+    if (form == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sea::ns_denoise_pipe6_dense_kernel, 384, 0);
     if (form == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sea::ns_denoise_pipe_big_kernel, 256, 0);
     if (form == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sea::ns_denoise_pipe_pair_kernel, sea::ns_pair_threads(), 0);
     if (form == 16) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sea::ns16k_pipe_kernel, 512, 0);
@@ -220,7 +229,7 @@ int sea_debug_ns_occupancy(int form)
 int sea_ns_kernel_form(int form)
 {
     const int prev = ns_form();
-    if (form >= 0 && form <= 5) g_ns_form.store(form);
+    if (form >= 0 && form <= 6) g_ns_form.store(form);
     return prev;
 }
 
@@ -242,7 +251,7 @@ int sea_ns_denoise_batch(const short *d_in, short *d_out, float *d_out_f32,
     a.tables = c->ns;
     a.n_utt = n_utt;
     const int form = ns_pick_form(n_utt, c->n_cu);
-    if (form == 2) a.prio_row = (d_order && n_utt > c->n_cu) ? c->n_cu : 0; /* rows of the longest-first launch order */
+    if (form == 2 || form == 3 || form == 6) a.prio_row = (d_order && n_utt > c->n_cu) ? c->n_cu : 0; /* rows of the longest-first launch order */
     return ns_launch(a, form, (hipStream_t)stream);
 }
 

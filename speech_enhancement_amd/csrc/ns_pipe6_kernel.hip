@@ -104,14 +104,33 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
      * utterances per CU.  At four per CU (configs[1], where the four-wave form runs at 2.20 ms) the placement of the roles on
      * the SIMDs decides: identity 3.19 ms, 0104352 (B0, S, N1, G1, FA, FB) 2.78 ms, the ten even / odd splits in wave order
      * 2.97-3.26 ms (round 3, tools/build_variant.sh -DSEA_NS6_PERM=...): none reaches the four-wave form. */
-#ifndef SEA_NS6_PERM
-#define SEA_NS6_PERM 0543210
+#ifndef SEA_P6_LRPT
+#define SEA_P6_LRPT 1
 #endif
-    const int role = (SEA_NS6_PERM >> (3 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6))) & 7;
+#ifndef SEA_NS6_PERM
+#define SEA_NS6_PERM 0014352
+#endif
+    const int role = ((a.perm6 ? a.perm6 : SEA_NS6_PERM) >> (3 * __builtin_amdgcn_readfirstlane(threadIdx.x >> 6))) & 7;
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
     const long long off = a.offsets[u];
     const long long nfr = a.lengths[u] / SEA_HOP;
     const long long niter = nfr + kDepth;
+    /* issue priority by remaining frames, the rule of the four-wave form (ns_pipe_kernel.hip, SEA_PRIO_LRPT): on whenever the
+     * launch has more utterances than CUs to put them on and an order whose first entry is the longest */
+    const bool lrpt = SEA_P6_LRPT && a.prio_row > 0 && a.order;
+    const long long longestFr = lrpt ? a.lengths[a.order[0]] / SEA_HOP : 0;
+    const float lrptScale = 32.0f / (float)(longestFr > 0 ? longestFr : 1);
+    const int lrptBias = lrpt ? (int)blockIdx.x / a.prio_row : 0;
+    auto prio_by_remaining = [&](long long i) {
+        if (SEA_P6_LRPT && lrpt && (i & 15) == 0) {
+            const int L = __builtin_amdgcn_readfirstlane((int)((float)(nfr - i) * lrptScale)) + lrptBias;
+            const int pr = (L + (int)((i >> 4) & 7)) >> 3;
+            if (pr >= 3) __builtin_amdgcn_s_setprio(3);
+            else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+    };
 
     for (int i = threadIdx.x; i < 2 * (kCirc + kMirror); i += 64 * kWaves) (&L.circ[0][0])[i] = 0.0f;
     for (int i = threadIdx.x; i < SEA_NMEL * 16; i += 64 * kWaves) L.idctT[i] = a.tables->idct[i >> 4][i & 15];
@@ -143,6 +162,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
         int tick = 0; /* frames seen since (and including) the first non-zero one */
         int onset = (int)nfr;
         for (long long i = 0; i < niter; ++i) {
+            prio_by_remaining(i);
             RecA &r = L.ra[i & 1];
             int valid = 0;
             bool actA = false;
@@ -189,6 +209,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
         Fft2Regs fft;
         load_fft2_regs<false>(fft, &a.tables->fft, lane, nullptr);
         for (long long i = 0; i < niter; ++i) {
+            prio_by_remaining(i);
             const long long g = i - 1; /* FA's iteration */
             if (g >= 0) {
                 const RecA &r = L.ra[g & 1];
@@ -225,6 +246,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
         NsFd fd;
         fd_init(fd);
         for (long long i = 0; i < niter; ++i) {
+            prio_by_remaining(i);
             const long long f = i - 2;
             if (f >= 0 && f < nfr) {
                 const RecPsd &r = L.p0[f & 1];
@@ -254,6 +276,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
         NsRegs s;
         regs_init(s, eps);
         for (long long i = 0; i < niter; ++i) {
+            prio_by_remaining(i);
             const long long f = i - 5;
             if (f >= 0 && f < nfr) {
                 const RecPsd &r = L.p1[f & 1];
@@ -285,6 +308,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
         NsRegs s;
         regs_init(s, C.eps);
         for (long long i = 0; i < niter; ++i) {
+            prio_by_remaining(i);
             const long long f = i - 6;
             if (f >= 0 && f < nfr) {
                 const RecN &r = L.rn[f & 1];
@@ -306,6 +330,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
         float dcX = 0.0f, dcY = 0.0f; /* prevSamples, NoiseSup.c:908-909 */
         int firstOut = -1;
         for (long long i = 0; i < niter; ++i) {
+            prio_by_remaining(i);
             /* (1) VAD log-energy (NoiseSup.c:386-391) of the frame pushed at i-1 = tick tp ("current frame" of
              *     tick tp+2); (2) in-order sum of denSigSE1 of the frame B0 finished at i-1; (3) DC-offset
              *     filter, int16 cast, store of the frame G1 finished at i-1 */
@@ -388,6 +413,18 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
 #define SEA_NS6_BLOCKS 6
 #endif
 __global__ __launch_bounds__(384, SEA_NS6_BLOCKS) void ns_denoise_pipe6_kernel(NsBatchArgs a)
+{
+    __shared__ p6::Pipe6Lds L;
+    p6::ns_pipe6_body<false>(a, L);
+}
+/* The same body compiled for SEVEN waves per SIMD (72 VGPRs, 8 spilled): the form for three or four utterances per CU
+ * (round 4).  With 80 VGPRs a SIMD holds six waves, four six-wave workgroups are exactly the 24 a CU then holds -- and the
+ * dispatcher, which deals the six waves of a workgroup 2 / 2 / 1 / 1 over the SIMDs, does not find room for the fourth: it
+ * waited for one of the first three to end (configs[1]: 3.20 ms, which rounds 1-3 read as "the six-wave form loses at four
+ * per CU").  One wave slot of slack per SIMD lets all four co-reside: 2.14 ms without priorities, **2.00-2.05 ms** with the
+ * issue priority by remaining frames and the wave -> role map below, against 2.08-2.13 for the four-wave form
+ * (profiles/r04_ns_six_wave_dense.txt). */
+__global__ __launch_bounds__(384, 7) void ns_denoise_pipe6_dense_kernel(NsBatchArgs a)
 {
     __shared__ p6::Pipe6Lds L;
     p6::ns_pipe6_body<false>(a, L);

@@ -34,6 +34,7 @@ struct NsBatchArgs {
     float *state;
     int resume;
     int frame_base;
+    int perm6;                 /* six-wave form: wave -> role map, three bits per wave, wave 0 lowest (0: the kernel's default) */
 };
 /* [2 x 640 stage buffers as 8-slot rings][12 x 64 per-lane spectra: noise, den, previous PSD of (lane, 64) x 2 stages]
  * [8 frame energies][8 denSigSE1 sums][8 speech-flag words][40 scalars] */
@@ -152,6 +153,7 @@ __global__ void ns_denoise_pipe_fd_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_slice_kernel(NsBatchArgs a);     /* time slices: state in / out (NsBatchArgs::state) */
 __global__ void ns_denoise_pipe_big_slice_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe6_kernel(NsBatchArgs a);    /* six waves per utterance (ns_pipe6_kernel.hip) */
+__global__ void ns_denoise_pipe6_dense_kernel(NsBatchArgs a); /* the same compiled for seven waves per SIMD: four workgroups per CU co-reside */
 __global__ void ns_denoise_pipe6_fd_kernel(NsBatchArgs a); /* + speech flags for the frame-dropping VAD */
 __global__ void ns_stream_kernel(NsStreamArgs a);
 __global__ void ns16k_stream_kernel(Ns16StreamArgs a);

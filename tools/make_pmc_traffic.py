@@ -39,7 +39,10 @@ def parse_max(path, counter):
     return out
 
 
-def valu_issue(sq1, mix1, k="ns_denoise_pipe_kernel"):
+HEADLINE = "ns_denoise_pipe6_dense_kernel"  # the kernel form configs[1] runs on since round 4 (capi.hip::ns_pick_form)
+
+
+def valu_issue(sq1, mix1, k=HEADLINE):
     """(vector instructions, priced issue clocks) per launch of the headline kernel from the SQ passes: every
     instruction at the f32 cost, f64 ones at the f64 cost, transcendentals at theirs.  (Packed-f32 instructions have
     no counter of their own and are priced as plain f32: the figure is a LOWER bound of the issue time.)"""
@@ -61,7 +64,7 @@ def main():
         big = sys.argv[i + 1:i + 5]
         del sys.argv[i:]
     fetch, write = parse(sys.argv[1], "FETCH_SIZE"), parse(sys.argv[2], "WRITE_SIZE")
-    keys = {"ns_denoise_pipe_kernel": "ns_denoise_kernel_bytes_per_launch", "resynth_fused_kernel": "resynth_bytes_per_launch",
+    keys = {HEADLINE: "ns_denoise_kernel_bytes_per_launch", "resynth_fused_kernel": "resynth_bytes_per_launch",
             "compceps_kernel": "compceps_bytes_per_launch", "rfft256_kernel": "rfft256_bytes_per_launch",
             "subband_kernel": "subband_bytes_per_launch", "irm_target_kernel": "irm_bytes_per_launch",
             "ns16k_pipe_kernel": "ns16k_bytes_per_launch"}
