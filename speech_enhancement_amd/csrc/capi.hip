@@ -104,6 +104,9 @@ void gammatone_host_tables(float *cf64, float *bw64, float *midEar64)
     memcpy(midEar64, g_gt_host.midEar, sizeof g_gt_host.midEar);
 }
 
+/* diagnostic (tools/ns6_perm_sweep.py): wave -> role map of the six-wave forms, three bits per wave, wave 0 lowest; 0 = the
+ * kernel's own.  Initialised from SEA_NS6_PERM (octal). */
+static std::atomic<int> g_ns6_perm{[] { const char *e = getenv("SEA_NS6_PERM"); return e ? (int)strtol(e, nullptr, 8) : 0; }()};
 /* Forms of the same arithmetic (identical results), chosen by how many utterances share a CU:
  *   <= 2 per CU  six waves per utterance: shortest frame period (the run time is one utterance's
  *                chain of frames)                                     SEA_NS_KERNEL=pipe6
@@ -138,8 +141,8 @@ int ns_launch(const sea::NsBatchArgs &a, int form, hipStream_t stream)
         hipLaunchKernelGGL(sea::ns_denoise_kernel, dim3(a.n_utt), dim3(64), 0, stream, a);
     else if (form == 3 || form == 6) {
         sea::NsBatchArgs b = a;
-        static const int perm_env = [] { const char *e = getenv("SEA_NS6_PERM"); return e ? (int)strtol(e, nullptr, 8) : 0; }();
-        if (perm_env) b.perm6 = perm_env; /* diagnostic: the wave -> role map of the six-wave form, octal, wave 0 rightmost */
+        const int perm = g_ns6_perm.load(); /* diagnostic: the wave -> role map of the six-wave form (sea_debug_ns6_perm / SEA_NS6_PERM) */
+        if (perm) b.perm6 = perm;
         if (form == 6) hipLaunchKernelGGL(sea::ns_denoise_pipe6_dense_kernel, dim3(a.n_utt), dim3(384), 0, stream, b);
         else hipLaunchKernelGGL(sea::ns_denoise_pipe6_kernel, dim3(a.n_utt), dim3(384), 0, stream, b);
     } else if (form == 4)
@@ -193,6 +196,11 @@ int sea_gammatone_channels(float *cf64, float *bw64, float *midEar64)
 }
 
 /* ------------------------------------------------------------------------------------------- */
+extern "C" int sea_debug_ns6_perm(int perm)
+{
+    return g_ns6_perm.exchange(perm);
+}
+
 /* kernel form override: 0 = by batch size; initialised from SEA_NS_KERNEL on first use */
 static std::atomic<int> g_ns_form{-1};
 static int ns_form()

@@ -104,6 +104,9 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
      * utterances per CU.  At four per CU (configs[1], where the four-wave form runs at 2.20 ms) the placement of the roles on
      * the SIMDs decides: identity 3.19 ms, 0104352 (B0, S, N1, G1, FA, FB) 2.78 ms, the ten even / odd splits in wave order
      * 2.97-3.26 ms (round 3, tools/build_variant.sh -DSEA_NS6_PERM=...): none reaches the four-wave form. */
+#ifndef SEA_P6_TAPS_RL
+#define SEA_P6_TAPS_RL 1
+#endif
 #ifndef SEA_P6_LRPT
 #define SEA_P6_LRPT 1
 #endif
@@ -255,12 +258,20 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                 if (valid && t >= 3) {
                     float *tmp = L.back[0].sq;
                     int bits = 0;
+                    /* SEA_P6_TAPS_RL: the filter taps as scalar operands (v_readlane), the filter's outputs in registers straight
+                     * into the stage-1 buffer -- two LDS round trips less on this role's chain (ns_core.h, fir_taps_rl) */
+                    float y01[2] = {0.0f, 0.0f};
                     ns_back<0, true, FD, false, true>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
-                                         L.frameEn[t & (kSlots - 1)], o.den, L.idctT, &fd, &bits);
+                                         L.frameEn[t & (kSlots - 1)], o.den, L.idctT, &fd, &bits, nullptr,
+                                         SEA_P6_TAPS_RL ? y01 : nullptr);
                     if (FD && lane == 0) L.fdFlags[t & (kSlots - 1)] = bits;
                     if (lane < 40) {
-                        const float2 v = *reinterpret_cast<const float2 *>(tmp + 2 * lane);
-                        slot_store(L.circ[1], t, lane, v.x, v.y);
+                        if (SEA_P6_TAPS_RL) {
+                            slot_store(L.circ[1], t, lane, y01[0], y01[1]);
+                        } else {
+                            const float2 v = *reinterpret_cast<const float2 *>(tmp + 2 * lane);
+                            slot_store(L.circ[1], t, lane, v.x, v.y);
+                        }
                     }
                 }
                 if (lane == 0) {
@@ -350,6 +361,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                 denSrc = r.den;
             }
             const bool haveOut = fo >= 0 && fo < nfr;
+            float2 vOut = make_float2(0.0f, 0.0f);
             if (haveOut) produced = L.ro[fo & 1].produced != 0;
             if (doVad) {
                 const float *frame = L.circ[0] + (tp & (kSlots - 1)) * kSlotLen;
@@ -377,7 +389,8 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                 }
                 if (doDen && lane == 0) L.denSum[td & (kSlots - 1)] = denTotal;
                 if (produced) {
-                    dc_verify(L.sdif, L.sout, dcY, y, lane);
+                    if (SEA_P6_TAPS_RL) vOut = dc_verify_take(L.sdif, L.sout, dcY, y, lane); /* check + output in one batch of reads */
+                    else dc_verify(L.sdif, L.sout, dcY, y, lane);
                     dcY = y;
                     if (firstOut < 0) firstOut = (int)fo;
                 }
@@ -386,7 +399,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                 if (lane < 40) {
                     uint32_t packed = 0u;
                     if (produced) {
-                        const float2 v = *reinterpret_cast<const float2 *>(&L.sout[2 * lane]);
+                        const float2 v = SEA_P6_TAPS_RL ? vOut : *reinterpret_cast<const float2 *>(&L.sout[2 * lane]);
                         packed = (uint32_t)cast_i16(v.x) | ((uint32_t)cast_i16(v.y) << 16);
                         if (outf) *reinterpret_cast<float2 *>(outf + fo * SEA_HOP + 2 * lane) = v;
                     }
