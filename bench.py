@@ -905,7 +905,7 @@ def run_rank(args):
         per_cu = batch.n_utt / 256.0
         kernel = {"single": "sea::ns_denoise_kernel", "pipe": "sea::ns_denoise_pipe_kernel", "pipe6": "sea::ns_denoise_pipe6_kernel",
                   "pipe6d": "sea::ns_denoise_pipe6_dense_kernel", "big": "sea::ns_denoise_pipe_big_kernel"}.get(forced) or (
-            "sea::ns_denoise_pipe6_kernel" if per_cu <= 2 else ("sea::ns_denoise_pipe6_dense_kernel" if per_cu <= 4 else "sea::ns_denoise_pipe_big_kernel"))
+            "sea::ns_denoise_pipe6_kernel" if per_cu <= 3 else ("sea::ns_denoise_pipe6_dense_kernel" if per_cu <= 4 else "sea::ns_denoise_pipe_big_kernel"))
         result = {
             "metric": "NoiseSup frames/sec (16 kHz, hop 80, 256-pt rfft, two-stage Wiener), batched",
             "value": value,

@@ -99,7 +99,7 @@ int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const
                        const int *d_first_out, const long long *d_ceps_cum, long long total_frames,
                        float *d_ceps, int *d_n_ceps, int n_utt, void *stream);
 /* sea_ns_denoise_batch picks one of several forms of the same kernel by batch size (all bit-identical):
- * 3 = six waves per utterance (up to 2 utterances per CU: shortest frame period), 6 = the same compiled so that four
+ * 3 = six waves per utterance (up to 3 utterances per CU: shortest frame period), 6 = the same compiled so that four
  * workgroups co-reside on a CU (up to 4 per CU; round 4), 4 = four waves, lower register use (larger batches), 2 = four waves
  * (the form for up to 4 per CU until round 4; the time-slice launches run on it), 1 = one wave per utterance; 5 = two utterances per
  * workgroup with their lane-sparse phases packed into one wave: 22 % fewer vector instructions per frame and slower

@@ -108,10 +108,10 @@ void gammatone_host_tables(float *cf64, float *bw64, float *midEar64)
  * kernel's own.  Initialised from SEA_NS6_PERM (octal). */
 static std::atomic<int> g_ns6_perm{[] { const char *e = getenv("SEA_NS6_PERM"); return e ? (int)strtol(e, nullptr, 8) : 0; }()};
 /* Forms of the same arithmetic (identical results), chosen by how many utterances share a CU:
- *   <= 2 per CU  six waves per utterance: shortest frame period (the run time is one utterance's
- *                chain of frames)                                     SEA_NS_KERNEL=pipe6
+ *   <= 3 per CU  six waves per utterance: shortest frame period (the run time is one utterance's
+ *                chain of frames; 768 utterances: 1.74 ms against 1.85 for the dense form)   SEA_NS_KERNEL=pipe6
  *   <= 4 per CU  six waves per utterance compiled for seven waves per SIMD, so that four workgroups
- *                co-reside on a CU (round 4; ns_pipe6_kernel.hip)     SEA_NS_KERNEL=pipe6d
+ *                co-reside on a CU (round 4; ns_pipe6_kernel.hip; 896: 1.89 ms against 2.44)   SEA_NS_KERNEL=pipe6d
  *   more         four waves, tables in LDS: six workgroups per CU     SEA_NS_KERNEL=big
  *   (not chosen) four waves, transform address tables in VGPRs: the form for <= 4 per CU until round 4, 4 % behind the
  *                dense six-wave form there; the time-slice launches of the host pipelines run on it   SEA_NS_KERNEL=pipe
@@ -123,7 +123,7 @@ int ns_pick_form(int n_inflight, int n_cu)
     /* (form 5, two utterances per workgroup with their lane-sparse phases packed into one wave -- ns_pipe2_kernel.hip -- has
      * 22 % fewer vector instructions per frame and is slower: 434 against 465 M frames/s on the configs[4] shard; never
      * chosen here, see that file's header) */
-    return forced ? forced : (n_inflight <= 2 * n_cu ? 3 : (n_inflight <= 4 * n_cu ? 6 : 4));
+    return forced ? forced : (n_inflight <= 3 * n_cu ? 3 : (n_inflight <= 4 * n_cu ? 6 : 4));
 }
 
 int ns_launch(const sea::NsBatchArgs &a, int form, hipStream_t stream)

@@ -1447,6 +1447,38 @@ __device__ __forceinline__ void ns_gain1(const float *psd, const float *P, const
     ns_idct_fir<true, true>(melOut, B, C, buf, dst, lane, idctLds);
 }
 
+/* ns_gain1 for the six-wave forms since round 4: the taps as scalar operands, the filter's outputs in registers, and what
+ * leaves the wave is the DC-offset filter's input differences d[n] = y[n] - y[n-1] (ns_fir_dif_rl) instead of y itself: the helper
+ * wave's chain starts from them without a pass of its own over the frame.  lastIn = y[79] of the previous filtered frame (this
+ * wave's state now; prevSamples, NoiseSup.c:908). */
+__device__ __forceinline__ void ns_gain1_dif(const float *psd, const float *P, const float *noise, float alfaGF,
+                                             const float *buf, BackLds &B, NsRegs &s, const NsConst &C, float *dif,
+                                             int lane, const float *idctLds, float &lastIn)
+{
+    const float nSigLo = psd[lane], nSigHi = psd[64], nzLo = noise[lane], nzHi = noise[64];
+    const bool psdOk = __ballot(!(ns_psd_in_domain(nSigLo) && ns_psd_in_domain(nSigHi))) == 0ull;
+    const bool noiseOk = __ballot(!(nzLo <= 0x1p29f && nzHi <= 0x1p29f)) == 0ull;
+    const bool fast = SEA_NS_FAST_DIV && psdOk && noiseOk && (s.psdOk[1] != 0);
+    s.psdOk[1] = psdOk ? 1 : 0;
+    float WLo, WHi;
+    if (fast) {
+        WLo = gain_bin<true>(sqrtf(P[lane]), sqrtf(nSigLo), nzLo, s.denLo[1]);
+        WHi = gain_bin<true>(sqrtf(P[64]), sqrtf(nSigHi), nzHi, s.denHi[1]);
+    } else {
+        WLo = gain_bin<false>(sqrtf(P[lane]), sqrtf(nSigLo), nzLo, s.denLo[1]);
+        WHi = gain_bin<false>(sqrtf(P[64]), sqrtf(nSigHi), nzHi, s.denHi[1]);
+    }
+    B.wbuf[lane] = WLo;
+    if (lane == 0) B.wbuf[64] = WHi;
+    wave_sync();
+    float melOut = ns_mel_fb(B, C, lane);
+    melOut = (float)((double)(alfaGF * melOut) + (1.0 - (double)alfaGF) * 1.0);
+    float d0, d1;
+    lastIn = ns_fir_dif_rl(fir_taps_rl(ns_idct_tap_rl(melOut, C.irWin, lane, idctLds)), buf, lane, lastIn, d0, d1);
+    if (lane < 40) *reinterpret_cast<float2 *>(dif + 2 * lane) = make_float2(d0, d1);
+    wave_sync();
+}
+
 /* One whole stage on the single-wave form: stage 0 deposits its 80 output samples in
  * ring[1][240..319], stage 1 in outb[0..79]. */
 template <int ST, bool FD = false>

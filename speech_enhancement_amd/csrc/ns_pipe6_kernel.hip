@@ -25,6 +25,29 @@ namespace sea {
 
 namespace p6 { /* everything of the six-wave form */
 
+/* timing-only diagnostic (-DSEA_NS6_TIMING): shader clocks workgroup 0's six roles spend working / waiting at the frame barrier
+ * -> g_ns6_timing[role * 2 + {0, 1}], [12] = frames; read through sea_debug_ns6_timing (tools/ns6_roles.py) */
+#ifdef SEA_NS6_TIMING
+__device__ unsigned long long g_ns6_timing[16];
+struct RoleTimer6 {
+    unsigned long long work = 0, wait = 0, t0 = 0, t1 = 0;
+    __device__ __forceinline__ void begin() { t0 = clock64(); }
+    __device__ __forceinline__ void mid() { t1 = clock64(); work += t1 - t0; }
+    __device__ __forceinline__ void end() { wait += clock64() - t1; }
+};
+#define NS6_T_DECL RoleTimer6 rt_
+#define NS6_T_BEGIN rt_.begin()
+#define NS6_T_MID rt_.mid()
+#define NS6_T_END rt_.end()
+#define NS6_T_FLUSH(r, n) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { g_ns6_timing[2 * (r)] = rt_.work; g_ns6_timing[2 * (r) + 1] = rt_.wait; g_ns6_timing[12] = (unsigned long long)(n); } } while (0)
+#else
+#define NS6_T_DECL
+#define NS6_T_BEGIN
+#define NS6_T_MID
+#define NS6_T_END
+#define NS6_T_FLUSH(r, n)
+#endif
+
 constexpr int kSlots = 8;
 constexpr int kSlotLen = SEA_HOP;
 constexpr int kCirc = kSlots * kSlotLen;
@@ -60,6 +83,8 @@ struct __attribute__((aligned(16))) Pipe6Lds {
     BackLds back[2];                /* scratch of B0 and G1 */
     float ssq[80], sdif[80], sout[80], szero[4]; /* scratch of S */
     float frameEn[kSlots], denSum[kSlots];
+    int vadTodo[2];                 /* SEA_P6_LOG_IN = 3: the ring entry whose log N1 takes at beat i + 1, by i & 1 (-1: none) */
+    float frameEnLog[kSlots];       /* SEA_P6_LIGHT_S: frameEn = 64 + sum of squares (S), frameEnLog = its log-energy (FA, one beat later) */
     int fdFlags[kSlots];
     float idctT[SEA_NMEL * 16];
     RecA ra[2];
@@ -96,7 +121,7 @@ __device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables 
     C.eps = t->eps;
 }
 
-template <bool FD>
+template <bool FD, bool LIGHT>
 __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
 {
     const int lane = threadIdx.x & 63;
@@ -106,6 +131,22 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
      * 2.97-3.26 ms (round 3, tools/build_variant.sh -DSEA_NS6_PERM=...): none reaches the four-wave form. */
 #ifndef SEA_P6_TAPS_RL
 #define SEA_P6_TAPS_RL 1
+#endif
+/* 1 (round 4; the forms for up to two utterances per CU, where the run time is one utterance's chain of frames): the helper
+ * wave S was this form's longest role (3397 clk per frame alone, B0 3089, G1 2985, N1 2623, FB 2608, FA 2268): (a) the VAD's
+ * log-energy (NoiseSup.c:391) is taken by the first transform wave FA one beat after S left the frame's sum of squares -- FA has
+ * ~1000 clk of slack, the value is consumed by B0 two beats later still (SEA_P6_LOG_IN = 3: by N1 instead); (b) G1 hands over the
+ * DC filter's input differences instead of the filtered frame (ns_gain1_dif), S's own pass over the frame goes.  S 3397 -> 2836,
+ * G1 2985 -> 3134, FA 2268 -> 2694: 256 utterances 1.777 -> 1.664 ms.  NOT in the dense form: at four workgroups per CU the step is
+ * a throughput limit and the same change costs 2 % there (1.99 against 1.95 ms). */
+#ifndef SEA_P6_LIGHT_S
+#define SEA_P6_LIGHT_S 1
+#endif
+#ifndef SEA_P6_LOG_IN /* which wave takes the VAD log with LIGHT: 0 FA itself, 3 N1 (FA only leaves the ring index) */
+#define SEA_P6_LOG_IN 0
+#endif
+#ifndef SEA_P6_S_CHUNKS
+#define SEA_P6_S_CHUNKS 10
 #endif
 #ifndef SEA_P6_LRPT
 #define SEA_P6_LRPT 1
@@ -140,10 +181,12 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
     if (threadIdx.x < 4) L.szero[threadIdx.x] = 0.0f;
     if (threadIdx.x < kSlots) {
         L.frameEn[threadIdx.x] = 0.0f;
+        L.frameEnLog[threadIdx.x] = 0.0f;
         L.denSum[threadIdx.x] = 0.0f;
     }
     if (threadIdx.x < 2) {
         const int k = threadIdx.x;
+        L.vadTodo[k] = -1;
         L.ra[k].valid = L.ra[k].valid1 = 0;
         L.p0[k].valid = L.p1[k].valid = 0;
         L.rd[k].valid = 0;
@@ -152,6 +195,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
         L.ro[k].produced = 0;
     }
     block_sync();
+    NS6_T_DECL;
 
     if (role == 0) {
         /* ---- FA: input + zero-frame gate (ParmInterface.c:244-251); first half of both transforms ---- */
@@ -164,8 +208,16 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
         uint32_t nextw = (lane < 40 && nfr > 0) ? in32[lane] : 0u;
         int tick = 0; /* frames seen since (and including) the first non-zero one */
         int onset = (int)nfr;
+        int vH1 = 0, tH1 = 0, vH2 = 0, tH2 = 0; /* (valid, tick) of frames i-1 and i-2 */
         for (long long i = 0; i < niter; ++i) {
+            NS6_T_BEGIN;
             prio_by_remaining(i);
+            if (LIGHT && SEA_P6_LOG_IN == 0 && vH2) { /* the log-energy of the sum S left one beat ago (the frame pushed at i-2 is tick tH2 + 2's "current frame") */
+                const int e = (tH2 + 2) & (kSlots - 1);
+                const float en = vad_frame_energy(L.frameEn[e]);
+                if (lane == 0) L.frameEnLog[e] = en;
+            }
+            if (LIGHT && SEA_P6_LOG_IN == 3 && lane == 0) L.vadTodo[i & 1] = vH2 ? ((tH2 + 2) & (kSlots - 1)) : -1;
             RecA &r = L.ra[i & 1];
             int valid = 0;
             bool actA = false;
@@ -198,20 +250,25 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                 r.valid1 = valid1;
                 r.tick1 = t1;
             }
+            vH2 = vH1, tH2 = tH1, vH1 = valid, tH1 = tick;
             if (actA || actB) {
                 wave_sync();
                 float e[8];
                 ns_window8(L.circ[0] + window_base(tick), actA, L.circ[1] + window_base(t1), actB, win8, lane, e);
                 rfft256_dual_lo<false>(e, L.work[i & 1], fft);
             }
+            NS6_T_MID;
             block_sync();
+            NS6_T_END;
         }
+        NS6_T_FLUSH(role, niter);
         if (FD && a.onset_out && lane == 0) a.onset_out[u] = onset;
     } else if (role == 1) {
         /* ---- FB: second half of both transforms, FFTtoPSD ---- */
         Fft2Regs fft;
         load_fft2_regs<false>(fft, &a.tables->fft, lane, nullptr);
         for (long long i = 0; i < niter; ++i) {
+            NS6_T_BEGIN;
             prio_by_remaining(i);
             const long long g = i - 1; /* FA's iteration */
             if (g >= 0) {
@@ -238,8 +295,11 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                     }
                 }
             }
+            NS6_T_MID;
             block_sync();
+            NS6_T_END;
         }
+        NS6_T_FLUSH(role, niter);
     } else if (role == 2) {
         /* ---- B0: BACK of stage 0; its 80 outputs enter the stage-1 buffer ---- */
         NsConst C;
@@ -249,6 +309,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
         NsFd fd;
         fd_init(fd);
         for (long long i = 0; i < niter; ++i) {
+            NS6_T_BEGIN;
             prio_by_remaining(i);
             const long long f = i - 2;
             if (f >= 0 && f < nfr) {
@@ -262,7 +323,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                      * into the stage-1 buffer -- two LDS round trips less on this role's chain (ns_core.h, fir_taps_rl) */
                     float y01[2] = {0.0f, 0.0f};
                     ns_back<0, true, FD, false, true>(r.psd, L.circ[0] + window_base(t), L.back[0], s, C, tmp, lane,
-                                         L.frameEn[t & (kSlots - 1)], o.den, L.idctT, &fd, &bits, nullptr,
+                                         (LIGHT ? L.frameEnLog : L.frameEn)[t & (kSlots - 1)], o.den, L.idctT, &fd, &bits, nullptr,
                                          SEA_P6_TAPS_RL ? y01 : nullptr);
                     if (FD && lane == 0) L.fdFlags[t & (kSlots - 1)] = bits;
                     if (lane < 40) {
@@ -279,15 +340,26 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                     o.tick = t;
                 }
             }
+            NS6_T_MID;
             block_sync();
+            NS6_T_END;
         }
+        NS6_T_FLUSH(role, niter);
     } else if (role == 3) {
         /* ---- N1: stage-1 noise tracking, noise-spectrum sum, gain-factor scalars ---- */
         const float eps = a.tables->eps;
         NsRegs s;
         regs_init(s, eps);
         for (long long i = 0; i < niter; ++i) {
+            NS6_T_BEGIN;
             prio_by_remaining(i);
+            if (LIGHT && SEA_P6_LOG_IN == 3 && i > 0) { /* the VAD log of the entry FA named one beat ago; B0 reads it one beat from now */
+                const int e = L.vadTodo[(i - 1) & 1];
+                if (e >= 0) {
+                    const float en = vad_frame_energy(L.frameEn[e]);
+                    if (lane == 0) L.frameEnLog[e] = en;
+                }
+            }
             const long long f = i - 5;
             if (f >= 0 && f < nfr) {
                 const RecPsd &r = L.p1[f & 1];
@@ -310,30 +382,40 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                     o.tick = t;
                 }
             }
+            NS6_T_MID;
             block_sync();
+            NS6_T_END;
         }
+        NS6_T_FLUSH(role, niter);
     } else if (role == 4) {
         /* ---- G1: stage-1 Wiener gains, mel, gain factorisation, IDCT, FIR ---- */
         NsConst C;
         load_back_const(C, a.tables, lane);
         NsRegs s;
         regs_init(s, C.eps);
+        float lastIn = 0.0f; /* LIGHT: y[79] of the previous filtered frame (prevSamples, NoiseSup.c:908) */
         for (long long i = 0; i < niter; ++i) {
+            NS6_T_BEGIN;
             prio_by_remaining(i);
             const long long f = i - 6;
             if (f >= 0 && f < nfr) {
                 const RecN &r = L.rn[f & 1];
                 RecOut &o = L.ro[f & 1];
                 const int produced = r.produced, t = r.tick;
-                if (produced)
+                if (produced && LIGHT)
+                    ns_gain1_dif(r.psd, r.P, r.noise, r.alfa, L.circ[1] + window_base(t), L.back[1], s, C, o.out, lane, L.idctT, lastIn);
+                else if (produced)
                     ns_gain1(r.psd, r.P, r.noise, r.alfa, L.circ[1] + window_base(t), L.back[1], s, C, o.out, lane, L.idctT);
                 if (lane == 0) {
                     o.produced = produced;
                     o.tick = t;
                 }
             }
+            NS6_T_MID;
             block_sync();
+            NS6_T_END;
         }
+        NS6_T_FLUSH(role, niter);
     } else {
         /* ---- S: the lane-grouped scalar chains (helper_chains) ---- */
         uint32_t *out32 = reinterpret_cast<uint32_t *>(a.out + off);
@@ -341,6 +423,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
         float dcX = 0.0f, dcY = 0.0f; /* prevSamples, NoiseSup.c:908-909 */
         int firstOut = -1;
         for (long long i = 0; i < niter; ++i) {
+            NS6_T_BEGIN;
             prio_by_remaining(i);
             /* (1) VAD log-energy (NoiseSup.c:386-391) of the frame pushed at i-1 = tick tp ("current frame" of
              *     tick tp+2); (2) in-order sum of denSigSE1 of the frame B0 finished at i-1; (3) DC-offset
@@ -372,7 +455,8 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                     L.ssq[64 + lane] = yv * yv;
                 }
             }
-            if (produced) {
+            const float *difS = LIGHT ? L.ro[fo & 1].out : L.sdif; /* LIGHT_S: G1 left the differences themselves */
+            if (produced && !LIGHT) {
                 const float *y2 = L.ro[fo & 1].out;
                 const float xm1 = (lane == 0) ? dcX : y2[lane - 1];
                 L.sdif[lane] = y2[lane] - xm1;
@@ -382,15 +466,15 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
             if (doVad || doDen || produced) {
                 wave_sync();
                 float vadSum, denTotal, y = dcY;
-                helper_chains<10>(L.ssq, denSrc, L.sdif, L.sout, L.szero, vadSum, denTotal, y, lane);
+                helper_chains<LIGHT ? SEA_P6_S_CHUNKS : 10>(L.ssq, denSrc, difS, L.sout, L.szero, vadSum, denTotal, y, lane);
                 if (doVad) {
-                    const float en = vad_frame_energy(vadSum);
+                    const float en = LIGHT ? vadSum : vad_frame_energy(vadSum); /* LIGHT_S: FA takes the log one beat later */
                     if (lane == 0) L.frameEn[(tp + 2) & (kSlots - 1)] = en;
                 }
                 if (doDen && lane == 0) L.denSum[td & (kSlots - 1)] = denTotal;
                 if (produced) {
-                    if (SEA_P6_TAPS_RL) vOut = dc_verify_take(L.sdif, L.sout, dcY, y, lane); /* check + output in one batch of reads */
-                    else dc_verify(L.sdif, L.sout, dcY, y, lane);
+                    if (SEA_P6_TAPS_RL) vOut = dc_verify_take(difS, L.sout, dcY, y, lane); /* check + output in one batch of reads */
+                    else dc_verify(difS, L.sout, dcY, y, lane);
                     dcY = y;
                     if (firstOut < 0) firstOut = (int)fo;
                 }
@@ -409,8 +493,11 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                     a.flags_out[off / 8 + 10 * fo] = (unsigned char)L.fdFlags[L.ro[fo & 1].tick & (kSlots - 1)];
                 wave_sync();
             }
+            NS6_T_MID;
             block_sync();
+            NS6_T_END;
         }
+        NS6_T_FLUSH(role, niter);
         if (a.first_out && lane == 0) a.first_out[u] = firstOut;
     }
 }
@@ -428,7 +515,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
 __global__ __launch_bounds__(384, SEA_NS6_BLOCKS) void ns_denoise_pipe6_kernel(NsBatchArgs a)
 {
     __shared__ p6::Pipe6Lds L;
-    p6::ns_pipe6_body<false>(a, L);
+    p6::ns_pipe6_body<false, SEA_P6_LIGHT_S != 0>(a, L);
 }
 /* The same body compiled for SEVEN waves per SIMD (72 VGPRs, 8 spilled): the form for three or four utterances per CU
  * (round 4).  With 80 VGPRs a SIMD holds six waves, four six-wave workgroups are exactly the 24 a CU then holds -- and the
@@ -440,13 +527,20 @@ __global__ __launch_bounds__(384, SEA_NS6_BLOCKS) void ns_denoise_pipe6_kernel(N
 __global__ __launch_bounds__(384, 7) void ns_denoise_pipe6_dense_kernel(NsBatchArgs a)
 {
     __shared__ p6::Pipe6Lds L;
-    p6::ns_pipe6_body<false>(a, L);
+    p6::ns_pipe6_body<false, false>(a, L); /* without the lighter helper wave: at four per CU it costs 2 % (1.99 against 1.95 ms) */
 }
 __global__ __launch_bounds__(384, 2) void ns_denoise_pipe6_fd_kernel(NsBatchArgs a)
 {
     __shared__ p6::Pipe6Lds L;
-    p6::ns_pipe6_body<true>(a, L);
+    p6::ns_pipe6_body<true, SEA_P6_LIGHT_S != 0>(a, L);
 }
 #endif
 
 } // namespace sea
+
+#if defined(SEA_NS6_TIMING) && !defined(SEA_NS_BODY_ONLY)
+extern "C" int sea_debug_ns6_timing(unsigned long long *out16)
+{
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(sea::p6::g_ns6_timing), 16 * sizeof(unsigned long long));
+}
+#endif
