@@ -67,6 +67,9 @@ struct NsConst {
 #ifndef SEA_NOISE_SAFE
 #define SEA_NOISE_SAFE 1 /* skip the noise range test after a frame that ran inside the fast-division domain (ns_back) */
 #endif
+#ifndef SEA_P6_G1_PK
+#define SEA_P6_G1_PK 1 /* six-wave forms' gain wave: lean square roots and packed gains inside the fast-division domain, as the four-wave forms */
+#endif
 #ifndef SEA_NS_STEADY
 #define SEA_NS_STEADY 1 /* branch-free FilterCalc of (bin lane, bin 64) side by side in the forms without register pairs */
 #endif
@@ -1432,7 +1435,16 @@ __device__ __forceinline__ void ns_gain1(const float *psd, const float *P, const
     const bool fast = SEA_NS_FAST_DIV && psdOk && noiseOk && (s.psdOk[1] != 0);
     s.psdOk[1] = psdOk ? 1 : 0;
     float WLo, WHi;
-    if (fast) {
+    if (fast && SEA_P6_G1_PK) { /* as filter_bins_fast: the lean square root (valid on the domain), the pair (lane, 64) through the packed form */
+        const ns_v2f nSig = {SEA_SQRT(nSigLo), SEA_SQRT(nSigHi)};
+        const ns_v2f Pq = {SEA_SQRT(P[lane]), SEA_SQRT(P[64])};
+        ns_v2f den = {s.denLo[1], s.denHi[1]};
+        const ns_v2f W = gain_bin2(Pq, nSig, ns_v2f{nzLo, nzHi}, den);
+        s.denLo[1] = den.x;
+        s.denHi[1] = den.y;
+        WLo = W.x;
+        WHi = W.y;
+    } else if (fast) {
         WLo = gain_bin<true>(sqrtf(P[lane]), sqrtf(nSigLo), nzLo, s.denLo[1]);
         WHi = gain_bin<true>(sqrtf(P[64]), sqrtf(nSigHi), nzHi, s.denHi[1]);
     } else {
@@ -1461,7 +1473,16 @@ __device__ __forceinline__ void ns_gain1_dif(const float *psd, const float *P, c
     const bool fast = SEA_NS_FAST_DIV && psdOk && noiseOk && (s.psdOk[1] != 0);
     s.psdOk[1] = psdOk ? 1 : 0;
     float WLo, WHi;
-    if (fast) {
+    if (fast && SEA_P6_G1_PK) { /* as filter_bins_fast: the lean square root (valid on the domain), the pair (lane, 64) through the packed form */
+        const ns_v2f nSig = {SEA_SQRT(nSigLo), SEA_SQRT(nSigHi)};
+        const ns_v2f Pq = {SEA_SQRT(P[lane]), SEA_SQRT(P[64])};
+        ns_v2f den = {s.denLo[1], s.denHi[1]};
+        const ns_v2f W = gain_bin2(Pq, nSig, ns_v2f{nzLo, nzHi}, den);
+        s.denLo[1] = den.x;
+        s.denHi[1] = den.y;
+        WLo = W.x;
+        WHi = W.y;
+    } else if (fast) {
         WLo = gain_bin<true>(sqrtf(P[lane]), sqrtf(nSigLo), nzLo, s.denLo[1]);
         WHi = gain_bin<true>(sqrtf(P[64]), sqrtf(nSigHi), nzHi, s.denHi[1]);
     } else {

@@ -121,7 +121,7 @@ __device__ __forceinline__ void load_back_const(NsConst &C, const sea_ns_tables 
     C.eps = t->eps;
 }
 
-template <bool FD, bool LIGHT>
+template <bool FD, bool LIGHT /* the VAD log leaves S */, bool DIFG1 = LIGHT /* G1 hands over the DC differences */>
 __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
 {
     const int lane = threadIdx.x & 63;
@@ -141,6 +141,12 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
  * a throughput limit and the same change costs 2 % there (1.99 against 1.95 ms). */
 #ifndef SEA_P6_LIGHT_S
 #define SEA_P6_LIGHT_S 1
+#endif
+#ifndef SEA_P6D_LOGMOVE /* the same two changes in the dense form, separately */
+#define SEA_P6D_LOGMOVE 0
+#endif
+#ifndef SEA_P6D_DIFG1
+#define SEA_P6D_DIFG1 0
 #endif
 #ifndef SEA_P6_LOG_IN /* which wave takes the VAD log with LIGHT: 0 FA itself, 3 N1 (FA only leaves the ring index) */
 #define SEA_P6_LOG_IN 0
@@ -402,7 +408,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                 const RecN &r = L.rn[f & 1];
                 RecOut &o = L.ro[f & 1];
                 const int produced = r.produced, t = r.tick;
-                if (produced && LIGHT)
+                if (produced && DIFG1)
                     ns_gain1_dif(r.psd, r.P, r.noise, r.alfa, L.circ[1] + window_base(t), L.back[1], s, C, o.out, lane, L.idctT, lastIn);
                 else if (produced)
                     ns_gain1(r.psd, r.P, r.noise, r.alfa, L.circ[1] + window_base(t), L.back[1], s, C, o.out, lane, L.idctT);
@@ -455,8 +461,8 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                     L.ssq[64 + lane] = yv * yv;
                 }
             }
-            const float *difS = LIGHT ? L.ro[fo & 1].out : L.sdif; /* LIGHT_S: G1 left the differences themselves */
-            if (produced && !LIGHT) {
+            const float *difS = DIFG1 ? L.ro[fo & 1].out : L.sdif; /* DIFG1: G1 left the differences themselves */
+            if (produced && !DIFG1) {
                 const float *y2 = L.ro[fo & 1].out;
                 const float xm1 = (lane == 0) ? dcX : y2[lane - 1];
                 L.sdif[lane] = y2[lane] - xm1;
@@ -466,7 +472,7 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
             if (doVad || doDen || produced) {
                 wave_sync();
                 float vadSum, denTotal, y = dcY;
-                helper_chains<LIGHT ? SEA_P6_S_CHUNKS : 10>(L.ssq, denSrc, difS, L.sout, L.szero, vadSum, denTotal, y, lane);
+                helper_chains<SEA_P6_S_CHUNKS>(L.ssq, denSrc, difS, L.sout, L.szero, vadSum, denTotal, y, lane);
                 if (doVad) {
                     const float en = LIGHT ? vadSum : vad_frame_energy(vadSum); /* LIGHT_S: FA takes the log one beat later */
                     if (lane == 0) L.frameEn[(tp + 2) & (kSlots - 1)] = en;
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(384, SEA_NS6_BLOCKS) void ns_denoise_pipe6_kernel(N
 __global__ __launch_bounds__(384, 7) void ns_denoise_pipe6_dense_kernel(NsBatchArgs a)
 {
     __shared__ p6::Pipe6Lds L;
-    p6::ns_pipe6_body<false, false>(a, L); /* without the lighter helper wave: at four per CU it costs 2 % (1.99 against 1.95 ms) */
+    p6::ns_pipe6_body<false, SEA_P6D_LOGMOVE != 0, SEA_P6D_DIFG1 != 0>(a, L);
 }
 __global__ __launch_bounds__(384, 2) void ns_denoise_pipe6_fd_kernel(NsBatchArgs a)
 {
