@@ -157,6 +157,15 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
 #ifndef SEA_P6_LRPT
 #define SEA_P6_LRPT 1
 #endif
+#ifndef SEA_P6_PRIO_LEVELS
+#define SEA_P6_PRIO_LEVELS 32
+#endif
+#ifndef SEA_P6_PRIO_STEP
+#define SEA_P6_PRIO_STEP 16
+#endif
+#ifndef SEA_P6_PRIO_ROWBIAS
+#define SEA_P6_PRIO_ROWBIAS 1
+#endif
 #ifndef SEA_NS6_PERM
 #define SEA_NS6_PERM 0014352
 #endif
@@ -169,12 +178,12 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
      * launch has more utterances than CUs to put them on and an order whose first entry is the longest */
     const bool lrpt = SEA_P6_LRPT && a.prio_row > 0 && a.order;
     const long long longestFr = lrpt ? a.lengths[a.order[0]] / SEA_HOP : 0;
-    const float lrptScale = 32.0f / (float)(longestFr > 0 ? longestFr : 1);
-    const int lrptBias = lrpt ? (int)blockIdx.x / a.prio_row : 0;
+    const float lrptScale = (float)SEA_P6_PRIO_LEVELS / (float)(longestFr > 0 ? longestFr : 1);
+    const int lrptBias = lrpt ? SEA_P6_PRIO_ROWBIAS * ((int)blockIdx.x / a.prio_row) : 0;
     auto prio_by_remaining = [&](long long i) {
-        if (SEA_P6_LRPT && lrpt && (i & 15) == 0) {
+        if (SEA_P6_LRPT && lrpt && (i & (SEA_P6_PRIO_STEP - 1)) == 0) {
             const int L = __builtin_amdgcn_readfirstlane((int)((float)(nfr - i) * lrptScale)) + lrptBias;
-            const int pr = (L + (int)((i >> 4) & 7)) >> 3;
+            const int pr = (L + (int)((i / SEA_P6_PRIO_STEP) & (SEA_P6_PRIO_LEVELS / 4 - 1))) / (SEA_P6_PRIO_LEVELS / 4);
             if (pr >= 3) __builtin_amdgcn_s_setprio(3);
             else if (pr == 2) __builtin_amdgcn_s_setprio(2);
             else if (pr == 1) __builtin_amdgcn_s_setprio(1);
