@@ -18,6 +18,15 @@
  *
  * All records between neighbouring stages are double-buffered by frame parity (written at one
  * iteration, read at the next); the two transform work areas alternate between FA and FB.
+ *
+ * Round 4: this is the form for up to FOUR utterances per CU, configs[1] included (capi.hip::ns_pick_form).  Up to three per CU
+ * ns_denoise_pipe6_kernel (80 VGPRs, the lighter helper wave: SEA_P6_LIGHT_S); for the fourth ns_denoise_pipe6_dense_kernel, the same
+ * body compiled for seven waves per SIMD -- with six, the dispatcher never found room for the fourth six-wave workgroup of a CU, which is
+ * what rounds 1-3 measured as "the six-wave form loses at four per CU" (see the comment at the kernels below).  With more than one
+ * utterance per CU the waves set their issue priority by the frames their utterance has left (prio_by_remaining, the rule of
+ * ns_pipe_kernel.hip), and the wave -> role map (SEA_NS6_PERM) puts B0 and S on the two oldest waves: among equal priorities a SIMD
+ * issues its oldest wave first.  configs[1]: 1.91-1.95 ms = 420-427 M frames/s (four-wave form 2.08-2.13);
+ * profiles/r04_ns_six_wave_dense.txt.
  */
 #include "ns_core.h"
 
