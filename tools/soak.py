@@ -25,7 +25,7 @@ def main():
     ref = None
     bad = 0
     for k in range(it):
-        form = (2, 4, 3, 2)[k % 4]           # pipe, big, pipe6, pipe
+        form = (6, 2, 4, 3, 6)[k % 5]        # dense six-wave (the configs[1] form), pipe, big, pipe6, dense
         lib.sea_ns_kernel_form(form)
         out, f32, first = sea.ns_denoise_batch(batch, want_f32=True)
         if ref is None:
