@@ -102,10 +102,11 @@ int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const
  * 3 = six waves per utterance (up to 3 utterances per CU: shortest frame period), 6 = the same compiled so that four
  * workgroups co-reside on a CU (up to 4 per CU; round 4), 4 = four waves, lower register use (larger batches), 2 = four waves
  * (the form for up to 4 per CU until round 4; the time-slice launches run on it), 1 = one wave per utterance; 5 = two utterances per
- * workgroup with their lane-sparse phases packed into one wave: 22 % fewer vector instructions per frame and slower
- * (an experiment kept under the parity tests, never chosen by batch size).
+ * workgroup with their lane-sparse phases packed into one wave: 22 % fewer vector instructions per frame and slower; 7 = one wave per
+ * utterance running every role in sequence (no workgroup barrier; register-bound at twelve utterances per CU: slower)
+ * (5 and 7: experiments kept under the parity tests, never chosen by batch size).
  * sea_ns_kernel_form(f) forces form f for later calls (0 = by batch size again; the SEA_NS_KERNEL
- * environment variable = single | pipe | pipe6 | pipe6d | big | pair sets the initial value); returns the previous one. */
+ * environment variable = single | pipe | pipe6 | pipe6d | big | pair | wave sets the initial value); returns the previous one. */
 int sea_ns_kernel_form(int form);
 /* The same for one TIME SLICE of every utterance: a batch may be cut along the time axis and run as one launch per
  * slice, so that a caller can upload slice k + 1 and download slice k - 1 while slice k is on the device

@@ -116,6 +116,8 @@ static std::atomic<int> g_ns6_perm{[] { const char *e = getenv("SEA_NS6_PERM"); 
  *   (not chosen) four waves, transform address tables in VGPRs: the form for <= 4 per CU until round 4, 4 % behind the
  *                dense six-wave form there; the time-slice launches of the host pipelines run on it   SEA_NS_KERNEL=pipe
  *   (never)      two utterances per workgroup, lane-sparse phases packed   SEA_NS_KERNEL=pair (experiment, slower)
+ *   (never)      one wave per utterance, the roles in sequence, no workgroup barrier (ns_wave_kernel.hip): 363 M frames/s on the
+ *                configs[4] shard against 465                           SEA_NS_KERNEL=wave (experiment, slower)
  * SEA_NS_KERNEL=single: one wave per utterance (the streaming plug-in's kernel), for A/B. */
 int ns_pick_form(int n_inflight, int n_cu)
 {
@@ -147,7 +149,10 @@ int ns_launch(const sea::NsBatchArgs &a, int form, hipStream_t stream)
         else hipLaunchKernelGGL(sea::ns_denoise_pipe6_kernel, dim3(a.n_utt), dim3(384), 0, stream, b);
     } else if (form == 4)
         hipLaunchKernelGGL(sea::ns_denoise_pipe_big_kernel, dim3(a.n_utt), dim3(256), 0, stream, a);
-    else if (form == 5)
+    else if (form == 7) {
+        const int per = sea::ns_wave_utts_per_block();
+        hipLaunchKernelGGL(sea::ns_denoise_wave_kernel, dim3((a.n_utt + per - 1) / per), dim3(64 * per), 0, stream, a);
+    } else if (form == 5)
         hipLaunchKernelGGL(sea::ns_denoise_pipe_pair_kernel, dim3((a.n_utt + 1) / 2), dim3(sea::ns_pair_threads()), 0, stream, a);
     else
         hipLaunchKernelGGL(sea::ns_denoise_pipe_kernel, dim3(a.n_utt), dim3(256), 0, stream, a);
@@ -215,6 +220,7 @@ static int ns_form()
         if (e && !strcmp(e, "big")) f = 4;
         if (e && !strcmp(e, "pair")) f = 5;
         if (e && !strcmp(e, "pipe6d")) f = 6;
+        if (e && !strcmp(e, "wave")) f = 7;
         g_ns_form.store(f);
     }
     return f;
@@ -237,7 +243,7 @@ int sea_debug_ns_occupancy(int form)
 int sea_ns_kernel_form(int form)
 {
     const int prev = ns_form();
-    if (form >= 0 && form <= 6) g_ns_form.store(form);
+    if (form >= 0 && form <= 7) g_ns_form.store(form);
     return prev;
 }
 

@@ -153,7 +153,9 @@ __global__ void ns_denoise_pipe_fd_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe_slice_kernel(NsBatchArgs a);     /* time slices: state in / out (NsBatchArgs::state) */
 __global__ void ns_denoise_pipe_big_slice_kernel(NsBatchArgs a);
 __global__ void ns_denoise_pipe6_kernel(NsBatchArgs a);    /* six waves per utterance (ns_pipe6_kernel.hip) */
-__global__ void ns_denoise_pipe6_dense_kernel(NsBatchArgs a); /* the same compiled for seven waves per SIMD: four workgroups per CU co-reside */
+__global__ void ns_denoise_pipe6_dense_kernel(NsBatchArgs a);
+__global__ void ns_denoise_wave_kernel(NsBatchArgs a);     /* one wave per utterance, several per workgroup (ns_wave_kernel.hip) */
+int ns_wave_utts_per_block(); /* the same compiled for seven waves per SIMD: four workgroups per CU co-reside */
 __global__ void ns_denoise_pipe6_fd_kernel(NsBatchArgs a); /* + speech flags for the frame-dropping VAD */
 __global__ void ns_stream_kernel(NsStreamArgs a);
 __global__ void ns16k_stream_kernel(Ns16StreamArgs a);

@@ -979,9 +979,9 @@ def test_ns_large_batch_kernel_form(oracle):
 
 
 def test_ns_all_kernel_forms_agree(oracle):
-    """sea_ns_denoise_batch chooses among six forms of the same arithmetic by batch size (six waves per
+    """sea_ns_denoise_batch chooses among the forms of the same arithmetic by batch size (six waves per
     utterance, compiled for six or for seven waves per SIMD / four waves / four waves with less register use / two utterances
-    per workgroup / one wave):
+    per workgroup / one wave per utterance, streaming kernel and role-sequence kernel):
     forced one by one on the mixed corpus
     AND on the fill / drain corpus (0..12 frames, odd and even counts, 1..5 leading zero frames), every form
     matches the oracle bit for bit -- int16 audio, float stream and the index of the first output frame."""
@@ -997,7 +997,7 @@ def test_ns_all_kernel_forms_agree(oracle):
     traces = [oracle.ns_trace(x, want_state=False) for x in utts]
     prev = lib.sea_ns_kernel_form(0)
     try:
-        for form in (1, 2, 3, 4, 5, 6):
+        for form in (1, 2, 3, 4, 5, 6, 7):
             lib.sea_ns_kernel_form(form)
             out, f32, first = sea.ns_denoise_batch(batch, want_f32=True)
             torch.cuda.synchronize()

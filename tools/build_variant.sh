@@ -11,7 +11,7 @@ base=$(basename $src .hip)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -fno-gpu-flush-denormals-to-zero -fno-slp-vectorize \
     -I$C "$@" -c $src -o /tmp/variant_$name.o
 objs=""
-for o in capi hostpipe mapping ns_kernel ns_pipe_kernel ns_pipe6_kernel ns_pipe2_kernel ns16k_kernel ns16k_pipe_kernel cc_kernel resynth_kernel irm_kernel; do
+for o in capi hostpipe mapping ns_kernel ns_pipe_kernel ns_pipe6_kernel ns_pipe2_kernel ns_wave_kernel ns16k_kernel ns16k_pipe_kernel cc_kernel resynth_kernel irm_kernel; do
   if [ "$o" = "$base" ] || [ "$o" = "${VARIANT_REPLACES:-}" ]; then objs="$objs /tmp/variant_$name.o"; else objs="$objs $C/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o $ROOT/ablate/libsea_$name.so $objs $C/sea_tables.o
