@@ -154,6 +154,31 @@ def test_ns_batch_order_invariant():
     assert torch.equal(a, b)
 
 
+def test_ns_four_per_cu_any_launch_order(oracle):
+    """1000 short utterances = four per CU: the dense six-wave form with all four workgroups of a CU resident and the issue
+    priority by remaining frames switched on.  The priority rule takes the batch's longest utterance from the FIRST entry of the
+    launch order; a caller may pass any permutation (then the rule is only less sharp): with the library's order, with a shuffled
+    one and with none the outputs are the same words, and a spread of utterances equals the oracle."""
+    import speech_enhancement_amd as sea
+    from speech_enhancement_amd import corpus
+    torch = _torch()
+    rng = np.random.default_rng(7)
+    utts = [corpus.synth_utterance(300 + k, 80 * int(n) + int(r)) for k, (n, r) in enumerate(zip(rng.integers(6, 60, 1000), rng.integers(0, 80, 1000)))]
+    batch = sea.PackedBatch.from_arrays(utts)
+    a, _, fa = sea.ns_denoise_batch(batch, use_order=True)
+    keep = batch.order.clone()
+    batch.order = keep[torch.randperm(len(utts), generator=torch.Generator().manual_seed(3)).to(keep.device)]
+    b, _, fb = sea.ns_denoise_batch(batch, use_order=True)
+    batch.order = keep
+    c, _, fc = sea.ns_denoise_batch(batch, use_order=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(fa, fb) and torch.equal(fa, fc)
+    got = batch.split(a, full_frames_only=True)
+    for u in range(0, len(utts), 37):
+        tr = oracle.ns_trace(utts[u], want_state=False)
+        assert np.array_equal(got[u], tr["out_i16"][: (len(utts[u]) // 80) * 80]), f"utterance {u} (L={len(utts[u])})"
+
+
 def test_compceps_vs_oracle(oracle):
     import speech_enhancement_amd as sea
     torch = _torch()
