@@ -40,7 +40,7 @@ namespace {
 /* timing-only diagnostic (-DSEA_RS_TIMING): per role, shader-clock cycles spent working and waiting
  * at the tile barrier, for workgroup 0 -> g_rs_timing[kernel*6 + role*2 + {0,1}] */
 #ifdef SEA_RS_TIMING
-__device__ unsigned g_rs_wg[4096 * 2]; /* fused kernel, per workgroup: start and end on the constant 100 MHz counter (low 32 bits) */
+__device__ unsigned g_rs_wg[4096 * 4]; /* fused kernel, per workgroup: start and end on the constant 100 MHz counter (low 32 bits), HW_ID, XCC_ID */
 __device__ unsigned long long g_rs_timing[32]; /* fwd R1,R2,R3 = 0..5; bwd R1,R2,W,SUM = 6..13; subband R1,R2,K,HC,W = 16..25 */
 struct RoleTimer {
     unsigned long long work = 0, wait = 0, t0 = 0, t1 = 0;
@@ -715,7 +715,11 @@ __global__ __launch_bounds__(256, 4) void resynth_fused_kernel(ResynthArgs a)
         tp.scale = 32.0f / (float)(2 * ((Lmax + kTile - 1) / kTile) + 7);
     }
 #ifdef SEA_RS_TIMING
-    if (threadIdx.x == 0 && blockIdx.x < 4096) g_rs_wg[2 * blockIdx.x] = (unsigned)wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_rs_wg[4 * blockIdx.x] = (unsigned)wall_clock64();
+        g_rs_wg[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        g_rs_wg[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+    }
 #endif
     resynth_fwd_body(a, S.f, role, lane, u, off, L, tp);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -723,7 +727,7 @@ __global__ __launch_bounds__(256, 4) void resynth_fused_kernel(ResynthArgs a)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     resynth_bwd_body(a, S.b, role, lane, u, off, L, tp);
 #ifdef SEA_RS_TIMING
-    if (threadIdx.x == 192 && blockIdx.x < 4096) g_rs_wg[2 * blockIdx.x + 1] = (unsigned)wall_clock64(); /* the SUM wave ends last */
+    if (threadIdx.x == 192 && blockIdx.x < 4096) g_rs_wg[4 * blockIdx.x + 1] = (unsigned)wall_clock64(); /* the SUM wave ends last */
 #endif
 }
 
@@ -943,7 +947,7 @@ __global__ __launch_bounds__(256) void selftest_div_kernel(const sea_gt_tables *
 #ifdef SEA_RS_TIMING
 extern "C" int sea_debug_rs_wg(unsigned *out, int n_wg)
 {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sea::g_rs_wg), (size_t)n_wg * 2 * sizeof(unsigned));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sea::g_rs_wg), (size_t)n_wg * 4 * sizeof(unsigned));
 }
 extern "C" int sea_debug_rs_timing(unsigned long long *out16)
 {

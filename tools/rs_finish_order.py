@@ -16,9 +16,9 @@ lib = ctypes.CDLL(sea.LIB_PATH)
 for _ in range(3): sea.resynth_batch(batch, masks, binary=False, out=out, scratch=scratch)
 torch.cuda.synchronize()
 n = 1024
-buf = (ctypes.c_uint * (2 * n))()
+buf = (ctypes.c_uint * (4 * n))()
 assert lib.sea_debug_rs_wg(buf, n) == 0
-a = np.frombuffer(buf, dtype=np.uint32).reshape(n, 2).astype(np.int64)
+a = np.frombuffer(buf, dtype=np.uint32).reshape(n, 4).astype(np.int64)
 t0 = a[:, 0].min()
 start = ((a[:, 0] - t0) & 0xffffffff) * 10e-3
 end = ((a[:, 1] - t0) & 0xffffffff) * 10e-3
@@ -29,3 +29,16 @@ for lo, hi in ((0, 256), (256, 512), (512, 768), (768, 1024)):
           "end_us median", round(float(np.median(end[lo:hi])), 1), "max", round(float(end[lo:hi].max()), 1))
 grp = end.reshape(4, 256).max(axis=0)
 print("per launch column: latest end_us  min", round(float(grp.min()), 1), "median", round(float(np.median(grp)), 1), "max", round(float(grp.max()), 1))
+# concurrently resident workgroups per CU (HW_ID: CU, SE; XCC_ID)
+key = (a[:, 3] & 0xF) * 1000 + ((a[:, 2] >> 13) & 0x7) * 100 + ((a[:, 2] >> 8) & 0xF)
+s0 = (a[:, 0] - t0) & 0xffffffff
+e0 = (a[:, 1] - t0) & 0xffffffff
+mx = []
+for k in np.unique(key):
+    ev = sorted([(t, 1) for t in s0[key == k]] + [(t, -1) for t in e0[key == k]])
+    cur = best = 0
+    for t, d in ev:
+        cur += d
+        best = max(best, cur)
+    mx.append(best)
+print("CUs", len(mx), "resident workgroups per CU at the same time: min / median / max over CUs", int(np.min(mx)), int(np.median(mx)), int(np.max(mx)))
