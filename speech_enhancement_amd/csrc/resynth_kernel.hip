@@ -790,7 +790,39 @@ __device__ __forceinline__ float haircell_step(HairCell &h, float kt)
     return h.hdt * h.c;
 }
 
+/* the same step with fewer vector instructions on the recurrence's wave (round 4): the pair (c, w) through packed operations --
+ * each half rounded like the scalar instruction -- and the three clamps as v_max_f32 against +0 instead of compare + select.
+ * The clamp differs from `if (x < 0) x = 0` only for NaN and for -0.0, neither of which the recurrence can produce: every input is
+ * finite (int16 audio through the gammatone cascade, kt in [0, gdt)), the state stays >= +0, and a sum or difference of finite
+ * values that is zero is +0 in round-to-nearest unless both operands are -0.  15 instead of 21 instructions per sample. */
+__device__ __forceinline__ void haircell_step_lean(HairCell &h, float kt)
+{
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    const float replenish = (h.q < 1.0f) ? (h.ymdt - h.ydt * h.q) : 0.0f; /* (double)q < 1.0 <=> q < 1.0f: the conversion is exact */
+    const float eject = kt * h.q;
+    const v2 cc = {h.c, h.c};
+    const v2 rl = v2{h.lplusrdt, h.rdt} * cc;      /* reuptakeandloss, reuptake */
+    const float reprocess = h.xdt * h.w;
+    const float q = h.q + replenish - eject + reprocess;
+    v2 cw = v2{h.c, h.w} + v2{eject, rl.y};        /* c + eject, w + reuptake */
+    cw = cw - v2{rl.x, reprocess};                 /* - reuptakeandloss, - reprocess */
+    h.q = __builtin_fmaxf(q, 0.0f);
+    h.c = __builtin_fmaxf(cw.x, 0.0f);
+    h.w = __builtin_fmaxf(cw.y, 0.0f);
+}
+#ifndef SEA_SB_HC_LEAN
+#define SEA_SB_HC_LEAN 1
+#endif
+
 constexpr int kSbStride = 66; /* int16 per tile row: 64 channels + 2 pad (33 words: conflict-free) */
+/* SEA_SB_CAST_IN_W (round 4): the hair cell's wave -- the longest role of subbband() by half (2850 clk per 16-sample tile against
+ * 1900 for the next) -- leaves its state c of every step where its input kt stood (the permeability tile, now a ring of three
+ * float tiles of row stride 66) and the transposing wave W, idle four fifths of a tile, takes hdt * c, the truncating cast and the
+ * store: four of the 29 vector instructions per sample leave the recurrence's wave.  Same operations on the same values. */
+#ifndef SEA_SB_CAST_IN_W
+#define SEA_SB_CAST_IN_W 1
+#endif
+constexpr int kKtStride = SEA_SB_CAST_IN_W ? 66 : 64, kKtBufs = SEA_SB_CAST_IN_W ? 3 : 2;
 
 } // namespace
 
@@ -798,8 +830,8 @@ __global__ __launch_bounds__(384) void subband_kernel(SubbandArgs a)
 {
     __shared__ RsLds S;
     __shared__ __attribute__((aligned(16))) float xs[kTile];
-    __shared__ __attribute__((aligned(16))) float ktile[2][kTile][64];
-    __shared__ __attribute__((aligned(16))) short otile[2][kTile * kSbStride];
+    __shared__ __attribute__((aligned(16))) float ktile[kKtBufs][kTile][kKtStride];
+    __shared__ __attribute__((aligned(16))) short otile[SEA_SB_CAST_IN_W ? 1 : 2][SEA_SB_CAST_IN_W ? 8 : kTile * kSbStride];
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int u = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
@@ -862,7 +894,7 @@ __global__ __launch_bounds__(384) void subband_kernel(SubbandArgs a)
             const long long jt = j - 2;
             if (jt >= 0 && jt < ntile) {
                 const float(*g)[64] = S.g[jt & 1];
-                float(*o)[64] = ktile[jt & 1];
+                float(*o)[kKtStride] = ktile[jt % kKtBufs];
 #pragma unroll
                 for (int t = 0; t < kTile; t += 2) o[t + par][lane] = haircell_kt(h, g[t + par][lane]);
             }
@@ -879,10 +911,19 @@ __global__ __launch_bounds__(384) void subband_kernel(SubbandArgs a)
             RS_T_BEGIN;
             const long long jt = j - 3;
             if (jt >= 0 && jt < ntile) {
-                const float(*k)[64] = ktile[jt & 1];
-                short *o = otile[jt & 1];
+                float(*k)[kKtStride] = ktile[jt % kKtBufs];
+                short *o = otile[SEA_SB_CAST_IN_W ? 0 : (jt & 1)];
 #pragma unroll
-                for (int t = 0; t < kTile; ++t) o[t * kSbStride + lane] = (short)cast_i16(haircell_step(h, k[t][lane]));
+                for (int t = 0; t < kTile; ++t) {
+                    if (SEA_SB_CAST_IN_W && SEA_SB_HC_LEAN) {
+                        haircell_step_lean(h, k[t][lane]);
+                        k[t][lane] = h.c;
+                    } else {
+                        const float v = haircell_step(h, k[t][lane]);
+                        if (SEA_SB_CAST_IN_W) k[t][lane] = h.c; /* W takes hdt * c and the cast */
+                        else o[t * kSbStride + lane] = (short)cast_i16(v);
+                    }
+                }
             }
             RS_T_MID;
             tile_sync();
@@ -894,17 +935,22 @@ __global__ __launch_bounds__(384) void subband_kernel(SubbandArgs a)
         int16_t *out = a.out + off * 64;
         const long long Lp = (L + 7) & ~7LL; /* row pitch of this utterance's [64][Lp] block */
         const int t = lane & 15, cg = lane >> 4;
+        HairCell hw;
+        haircell_init(hw);
+        const float hdtW = hw.hdt;
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
             const long long jt = j - 4;
             if (jt >= 0 && jt < ntile) {
                 const long long n = jt * kTile + t;
-                const short *o = otile[jt & 1] + t * kSbStride;
+                const short *o = otile[SEA_SB_CAST_IN_W ? 0 : (jt & 1)] + (SEA_SB_CAST_IN_W ? 0 : t * kSbStride);
+                const float *cf = &ktile[jt % kKtBufs][t][0];
                 if (n < L) {
 #pragma unroll
                     for (int k = 0; k < 16; ++k) {
                         const int c = 4 * k + cg;
-                        out[c * Lp + n] = o[c];
+                        if (SEA_SB_CAST_IN_W) out[c * Lp + n] = (short)cast_i16(hdtW * cf[c]); /* extractwav.cpp:255, :85-88 */
+                        else out[c * Lp + n] = o[c];
                     }
                 }
             }
