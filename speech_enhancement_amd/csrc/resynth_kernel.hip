@@ -140,6 +140,9 @@ __device__ __forceinline__ void tile_sync()
  * ns_pipe_kernel.hip: SEA_PRIO_LRPT): every wave counts its tile barriers down and, every 64 tiles, sets s_setprio from
  * 32 * remaining / (the batch's longest utterance) dithered over eight consecutive evaluations into the four hardware
  * levels, so that the utterances sharing a CU converge on a common finishing time.  scale = 0: off. */
+#ifndef SEA_RS_FEED_W3
+#define SEA_RS_FEED_W3 1
+#endif
 #ifndef SEA_RS_LRPT
 #define SEA_RS_LRPT 1
 #endif
@@ -314,7 +317,7 @@ namespace {
 struct __attribute__((aligned(16))) FwdLds {
     v2f pq[2][kTile][64]; /* R1 -> R2: new (p1,q1) */
     v2f pa[2][kTile][64]; /* R2 -> R3: partial sums A */
-    float xs[kTile];
+    float xs[2][kTile]; /* SEA_RS_FEED_W3: the input samples of tile j at [j & 1], deposited one tile ahead by the fourth wave */
 };
 
 /* roles 0..2 work; any further wave of the workgroup only keeps the barrier count (fused kernel) */
@@ -323,21 +326,32 @@ __device__ __forceinline__ void resynth_fwd_body(const ResynthArgs &a, FwdLds &S
 {
     v2f(*pq)[kTile][64] = S.pq;
     v2f(*pa)[kTile][64] = S.pa;
-    float *xs = S.xs;
     const long long ntile = (L + kTile - 1) / kTile, niter = ntile + 2;
+    const int nwaves = (int)(blockDim.x >> 6);
     RS_T_DECL;
     if (role > 2) {
-        for (long long j = 0; j < niter; ++j) tile_sync(tp);
+        /* SEA_RS_FEED_W3 (round 4): the fused kernel's fourth wave, idle during this pass, converts and deposits the input samples of
+         * tile j + 1 while the cascade works on tile j: the first cascade wave R1 -- the longest role of the pass -- no longer pays a
+         * store / fence / load round trip per tile for them */
+        const int16_t *in = a.in + off;
+        InFeed feed;
+        if (SEA_RS_FEED_W3 && role == 3) feed.start(in, L, lane);
+        for (long long j = 0; j < niter; ++j) {
+            if (SEA_RS_FEED_W3 && role == 3 && j + 1 < ntile) feed.tile(in, L, j + 1, lane, S.xs[(j + 1) & 1]);
+            tile_sync(tp);
+        }
     } else if (role == 0) {
         const int16_t *in = a.in + off;
         const GtCoef C = gt_coef(a.tables->f1[lane], a.tables->f2[lane]);
         GtLo s = {};
         InFeed feed;
         feed.start(in, L, lane); /* extractwav.cpp:55-58 */
+        const bool ownFeed = !(SEA_RS_FEED_W3 && nwaves > 3); /* the three-wave kernel of the split form feeds itself */
         for (long long j = 0; j < niter; ++j) {
             RS_T_BEGIN;
             if (j < ntile) {
-                feed.tile(in, L, j, lane, xs);
+                float *xs = S.xs[j & 1];
+                if (ownFeed || j == 0) feed.tile(in, L, j, lane, xs);
                 wave_sync();
                 v2f(*o)[64] = pq[j & 1];
 #pragma unroll
