@@ -31,6 +31,10 @@
  */
 #include "ns_core.h"
 
+#ifndef SEA16P_LOG_IN_S
+#define SEA16P_LOG_IN_S 1
+#endif
+
 namespace sea {
 
 namespace p16 {
@@ -346,7 +350,9 @@ __device__ __forceinline__ void back16(StreamLds &L, const Tab &T, const float *
         if (nb < 2147483647) nb++;
         s.nbFrame[ST] = nb;
     }
-    if (ST == 0) vad_update(s, vad_frame_energy(frameSum)); /* _VAD_ (:350-421) on the sum S left at intake */
+    /* _VAD_ (:350-421).  SEA16P_LOG_IN_S (round 4): the helper wave S, which idles ~3500 clk of a beat, took the log-energy of the
+     * sum it left at intake; this wave -- the longest role -- only updates the VAD with it */
+    if (ST == 0) vad_update(s, SEA16P_LOG_IN_S ? frameSum : vad_frame_energy(frameSum));
     const int nb16 = (int)(short)s.nbFrame[ST];
     float nSigv[3], Pv[3], noisev[3], denv[3], Wv[3];
     bool inDomain = true;
@@ -792,7 +798,8 @@ __global__ void __launch_bounds__(256 * p16::kStreams, 4) ns16k_pipe_kernel(Ns16
                 const float *fr = L.circ[0] + (tk & (kSlots - 1)) * kHop;
                 float acc = 64.0f;
                 for (int n = 0; n < kHop; ++n) acc += fr[n] * fr[n];
-                if (lane == 0) L.frameEn[tk & (kSlots - 1)] = acc;
+                const float accEn = SEA16P_LOG_IN_S ? vad_frame_energy(acc) : acc;
+                if (lane == 0) L.frameEn[tk & (kSlots - 1)] = accEn;
             }
             wave_sync();
         }
@@ -874,7 +881,8 @@ __global__ void __launch_bounds__(256 * p16::kStreams, 4) ns16k_pipe_kernel(Ns16
                         valid = 1;
                         tick++;
                         slot_store3(L.circ[0], tick, lane, x);
-                        if (lane == 0) L.frameEn[tick & (kSlots - 1)] = vadSum;
+                        const float vadEn = SEA16P_LOG_IN_S ? vad_frame_energy(vadSum) : vadSum;
+                        if (lane == 0) L.frameEn[tick & (kSlots - 1)] = vadEn;
                     }
                     if (lane == 0) {
                         L.rin[fi & 1].valid = valid;
