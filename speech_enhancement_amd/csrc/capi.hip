@@ -408,7 +408,10 @@ int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const
     a.tables = c->cc;
     a.n_utt = n_utt;
     const long long nslot = total_frames / 16 + n_utt; /* tile slots of 16 frames (cc_kernel.hip, kCcT) */
-    const long long grid = nslot < 8192 ? nslot : 8192;
+#ifndef SEA_CC_GRID
+#define SEA_CC_GRID 8192
+#endif
+    const long long grid = nslot < SEA_CC_GRID ? nslot : SEA_CC_GRID;
     hipLaunchKernelGGL(sea::compceps_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return 0;

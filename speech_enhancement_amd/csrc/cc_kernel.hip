@@ -197,9 +197,6 @@ constexpr int kCcT = SEA_CC_TILE;
 #ifndef SEA_CC_LAT
 #define SEA_CC_LAT 0
 #endif
-#ifndef SEA_CC_MELW_LDS
-#define SEA_CC_MELW_LDS 0 /* (in LDS: 15.6 KB per wave, ten waves per CU instead of twelve: 0.83 -> 1.00 ms) */
-#endif
 #ifndef SEA_CC_WAVES
 #define SEA_CC_WAVES 3 /* waves per SIMD the register allocation leaves room for (LDS allows twelve waves per CU) */
 #endif
@@ -231,12 +228,10 @@ struct CcGeom {
 template <bool SHARED, int T = kCcT>
 struct __attribute__((aligned(16))) CcTileLds {
     float span[(CcGeom<SHARED, T>::SPAN + 3) & ~3];
-    float work[512];
-    float pw[2][152];                 /* 129 power bins per frame, zeros behind (the mel taps read past 128) */
+    float work[512];                  /* the dual transform's work area; after the tile's last pair, its T x 14 output rows */
+    float pw[2][SEA_CC_PWROW];        /* 129 power bins per frame, zeros behind (the mel taps read past 128) */
     float fb[T][24];
     float dctT[SEA_CC_NCHAN * 16];
-    float outb[T * SEA_CC_NCEP];
-    float melW[SEA_CC_MELW_LDS ? SEA_CC_TAPS * 32 : 4]; /* [tap][band]: the 22 triangle weights of a band (32 lanes read 32 banks) */
 };
 
 struct CcTileConst {
@@ -244,8 +239,8 @@ struct CcTileConst {
     float win8[8];
     int qd[8], qm[8];                 /* word offsets of Data[idx], Data[idx-1] from the frame's base; qd < 0: idx >= 200 */
     unsigned pa[4], nyq;              /* byte offsets in a work area: Re(l), Im(l), Re(l+64), Im(l+64); x[128] */
-    int melStart;
-    float melW[SEA_CC_MELW_LDS ? 1 : SEA_CC_TAPS];
+    int melBase, melFb;               /* this lane's (frame, band) of the mel pass: sea_tables.h, melLaneBase */
+    float melW[SEA_CC_TAPS2];
     float floorFB, floorE;
 };
 
@@ -272,20 +267,36 @@ __device__ __forceinline__ void load_cc_tile_const(CcTileConst &C, CcTileLds<SHA
     C.pa[2] = fft_swz((unsigned)lane + 64u);
     C.pa[3] = fft_swz(192u - (unsigned)lane);
     C.nyq = fft_swz(128u);
-    const int band = lane & 31;
-    C.melStart = (band < SEA_CC_NCHAN) ? t->melStart[band] : 0;
-    if (SEA_CC_MELW_LDS) {
-        for (int i = lane; i < SEA_CC_TAPS * 32; i += kLanes) L.melW[i] = ((i & 31) < SEA_CC_NCHAN) ? t->melW[i >> 5][i & 31] : 0.0f;
-    } else {
+    C.melBase = t->melLaneBase[lane];
+    C.melFb = t->melLaneFb[lane];
 #pragma unroll
-        for (int i = 0; i < (SEA_CC_MELW_LDS ? 1 : SEA_CC_TAPS); ++i) C.melW[i] = (band < SEA_CC_NCHAN) ? t->melW[i][band] : 0.0f;
-    }
+    for (int i = 0; i < SEA_CC_TAPS2; ++i) C.melW[i] = t->melLaneW[i][lane];
     C.floorFB = t->floorFB;
     C.floorE = t->floorE;
     for (int i = lane; i < SEA_CC_NCHAN * 16; i += kLanes) L.dctT[i] = t->dctT[i >> 4][i & 15];
-    for (int i = lane; i < 2 * 152; i += kLanes) (&L.pw[0][0])[i] = 0.0f;
+    for (int i = lane; i < 2 * SEA_CC_PWROW; i += kLanes) (&L.pw[0][0])[i] = 0.0f;
     wave_sync();
 }
+
+/* timing-only diagnostic (-DSEA_CC_TIMING, tools/cc_phases.py): shader clocks workgroup 0 of compceps_kernel spends per step of a tile */
+#ifdef SEA_CC_TIMING
+__device__ unsigned long long g_cc_ck[8];
+extern "C" int sea_cc_timing(unsigned long long *out8, int reset)
+{
+    if (reset) {
+        unsigned long long z[8] = {};
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_cc_ck), z, sizeof z) != hipSuccess;
+    }
+    return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_cc_ck), 8 * sizeof(unsigned long long)) != hipSuccess;
+}
+__device__ unsigned g_cc_wave[16384 * 4]; /* per wave of compceps_kernel: start, end (constant 100 MHz counter), HW_ID, XCC_ID */
+extern "C" int sea_cc_waves(unsigned *out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cc_wave), (size_t)n * 4 * sizeof(unsigned)) != hipSuccess; }
+#define CC_CK_START unsigned long long cck_ = clock64()
+#define CC_CK(k) do { const unsigned long long c_ = clock64(); if (SHARED && blockIdx.x == 0 && threadIdx.x == 0) g_cc_ck[k] += c_ - cck_; cck_ = c_; } while (0)
+#else
+#define CC_CK_START
+#define CC_CK(k)
+#endif
 
 /* the staged tile -> nv rows of 14 coefficients at dst */
 template <bool SHARED, int T = kCcT>
@@ -294,6 +305,7 @@ __device__ __forceinline__ void cc_tile(CcTileLds<SHARED, T> &L, const CcTileCon
     constexpr int FS = CcGeom<SHARED, T>::FS;
     /* logE (CompCeps.c:413-423): lane f sums the squares of frame f in sample order */
     float logE; /* three ranges of the walk, each with a constant pad */
+    CC_CK_START;
     {
         const float *p = L.span + FS * (lane & (T - 1));
         float acc = 0.0f;
@@ -312,6 +324,7 @@ __device__ __forceinline__ void cc_tile(CcTileLds<SHARED, T> &L, const CcTileCon
         }
         logE = (acc < C.floorE) ? (float)-50.0 : cc_logf(acc);
     }
+    CC_CK(1);
     const int npair = (nv + 1) >> 1;
     for (int pr = 0; pr < npair; ++pr) {
         const int h = lane >> 5;
@@ -344,19 +357,22 @@ __device__ __forceinline__ void cc_tile(CcTileLds<SHARED, T> &L, const CcTileCon
             }
         }
         wave_sync();
-        /* 23 mel triangles (DoMelFB, MelProc.c:82-104): lane = (frame, band) */
-        {
-            const int band = lane & 31;
-            if (band < SEA_CC_NCHAN && act) {
-                const float *q = L.pw[h] + C.melStart;
-                float acc = 0.0f;
+        /* 23 mel triangles (DoMelFB, MelProc.c:82-104): lane = one (frame, band) of the pair, dealt so that the aligned
+         * pairs the lanes of a group read lie on different banks (round 4: 3-way conflicts on every tap before) */
+        if (C.melFb >= 0 && 2 * pr + (C.melFb >= 24 ? 1 : 0) < nv) {
+            const float2 *q = reinterpret_cast<const float2 *>(&L.pw[0][0] + C.melBase);
+            float acc = 0.0f;
 #pragma unroll
-                for (int i = 0; i < SEA_CC_TAPS; ++i) acc = acc + q[i] * (SEA_CC_MELW_LDS ? L.melW[i * 32 + band] : C.melW[SEA_CC_MELW_LDS ? 0 : i]);
-                L.fb[f][band] = acc;
+            for (int i = 0; i < SEA_CC_TAPS2 / 2; ++i) {
+                const float2 v = q[i];
+                acc = acc + v.x * C.melW[2 * i];
+                acc = acc + v.y * C.melW[2 * i + 1];
             }
+            (&L.fb[2 * pr][0])[C.melFb] = acc;
         }
         wave_sync();
     }
+    CC_CK(2);
     /* natural log with floor (:509-513): lane = (frame, band) flattened */
     for (int idx = lane; idx < nv * SEA_CC_NCHAN; idx += kLanes) {
         const int f = idx / SEA_CC_NCHAN, b = idx - f * SEA_CC_NCHAN;
@@ -364,18 +380,21 @@ __device__ __forceinline__ void cc_tile(CcTileLds<SHARED, T> &L, const CcTileCon
         L.fb[f][b] = (v < C.floorFB) ? (float)-10.0 : cc_logf(v);
     }
     wave_sync();
+    CC_CK(3);
     /* DCT (:203-227): lane = (frame, coefficient) flattened; c = 12 is c0, logE goes to c = 13 */
     for (int idx = lane; idx < nv * 13; idx += kLanes) {
         const int f = idx / 13, c = idx - f * 13;
         float acc = 0.0f;
 #pragma unroll
         for (int j = 0; j < SEA_CC_NCHAN; ++j) acc += L.fb[f][j] * L.dctT[j * 16 + c];
-        L.outb[f * SEA_CC_NCEP + c] = acc;
+        L.work[f * SEA_CC_NCEP + c] = acc;
     }
-    if (lane < nv) L.outb[lane * SEA_CC_NCEP + 13] = logE;
+    if (lane < nv) L.work[lane * SEA_CC_NCEP + 13] = logE;
     wave_sync();
-    for (int idx = lane; idx < nv * SEA_CC_NCEP; idx += kLanes) dst[idx] = L.outb[idx];
+    CC_CK(4);
+    for (int idx = lane; idx < nv * SEA_CC_NCEP; idx += kLanes) dst[idx] = L.work[idx];
     wave_sync();
+    CC_CK(5);
 }
 
 } // namespace
@@ -412,12 +431,19 @@ __global__ __launch_bounds__(64) void compceps_frames_kernel(const float *data20
 }
 
 #ifndef SEA_CC_MINW
-#define SEA_CC_MINW 1
+#define SEA_CC_MINW 3 /* 168 VGPRs, no spilled vector register; left to itself the allocator takes 193 = two waves per SIMD */
 #endif
 __global__ __launch_bounds__(64, SEA_CC_MINW) void compceps_kernel(CepsArgs a)
 {
     __shared__ CcTileLds<true> L;
     const int lane = threadIdx.x;
+#ifdef SEA_CC_TIMING
+    if (lane == 0 && blockIdx.x < 16384) {
+        g_cc_wave[4 * blockIdx.x] = (unsigned)wall_clock64();
+        g_cc_wave[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        g_cc_wave[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+    }
+#endif
     CcTileConst C;
     load_cc_tile_const<true>(C, L, a.tables, lane);
     /* tile slots: utterance u owns slots [ceps_cum[u] / T + u, ceps_cum[u+1] / T + u + 1), at least
@@ -443,6 +469,10 @@ __global__ __launch_bounds__(64, SEA_CC_MINW) void compceps_kernel(CepsArgs a)
         const int nv = (int)(left < 0 ? 0 : (left > nrow ? nrow : left));
         float *dst = a.ceps + (c0 + j0) * SEA_CC_NCEP;
         if (nv > 0) {
+#ifdef SEA_CC_TIMING
+            constexpr bool SHARED = true; /* (CC_CK's switch) */
+#endif
+            CC_CK_START;
             /* span word x = Data[x-1] of frame j0: the float NoiseSup stream from sample 80 (f0 + j0) - 1 on;
              * Data[-1] of the utterance's very first cepstral frame is the zero before the first output */
             const float *cur0 = a.den_f32 + a.offsets[u] + (f0 + j0) * SEA_HOP;
@@ -468,10 +498,17 @@ __global__ __launch_bounds__(64, SEA_CC_MINW) void compceps_kernel(CepsArgs a)
                 }
             }
             wave_sync();
+            CC_CK(0);
+#ifdef SEA_CC_TIMING
+            if (blockIdx.x == 0 && lane == 0) g_cc_ck[7] += 1;
+#endif
             cc_tile<true>(L, C, nv, dst, lane);
         }
         for (int idx = nv * SEA_CC_NCEP + lane; idx < nrow * SEA_CC_NCEP; idx += kLanes) dst[idx] = 0.0f;
     }
+#ifdef SEA_CC_TIMING
+    if (lane == 0 && blockIdx.x < 16384) g_cc_wave[4 * blockIdx.x + 1] = (unsigned)wall_clock64();
+#endif
 }
 
 /* ==================================================================================================

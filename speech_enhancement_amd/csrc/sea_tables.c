@@ -311,6 +311,63 @@ void sea_build_ns_tables(sea_ns_tables *t)
     t->eps = (float)exp(-10.0); /* NS_EPS, NoiseSup.h:32 */
 }
 
+/* lane map of the tiled kernels' mel pass (sea_tables.h, melLaneBase): items = (frame h of the pair, band b); item i may sit in
+ * lane group g = 0 / 1 (lanes 0-31 / 32-63: the two halves a ds_read_b64 is served in) with its first bin at an even
+ * base <= start(b), as long as base + SEA_CC_TAPS2 still covers the band; the pair of banks it then reads is
+ * ((base + SEA_CC_PWROW h) / 2) mod 32 (+ i for tap pair i: the same shift for every lane).  Augmenting-path matching of the
+ * items onto the 2 x 32 (group, bank pair) slots; aborts if the 46 items do not all find one (they do: checked at build). */
+typedef struct { int h, b, slot, base; } mel_item_t;
+static int mel_try(const band_t *B, mel_item_t *it, int n, int i, int *owner, char *seen)
+{
+    int base, g;
+    for (base = B[it[i].b].start & ~1; base >= 0 && B[it[i].b].start - base + B[it[i].b].len <= SEA_CC_TAPS2; base -= 2)
+        for (g = 0; g < 2; g++) {
+            int slot = 32 * g + ((base + SEA_CC_PWROW * it[i].h) / 2) % 32;
+            if (seen[slot]) continue;
+            seen[slot] = 1;
+            if (owner[slot] < 0 || mel_try(B, it, n, owner[slot], owner, seen)) {
+                owner[slot] = i;
+                it[i].slot = slot;
+                it[i].base = base;
+                return 1;
+            }
+        }
+    return 0;
+}
+
+static void cc_mel_lanes(const band_t *B, sea_cc_tables *t)
+{
+    mel_item_t it[2 * SEA_CC_NCHAN];
+    int owner[64], n = 0, i, j, g, fill[2] = {0, 0};
+    char seen[64];
+    for (i = 0; i < 64; i++) owner[i] = -1;
+    for (i = 0; i < 2; i++)
+        for (j = 0; j < SEA_CC_NCHAN; j++) { it[n].h = i; it[n].b = j; it[n].slot = -1; it[n].base = 0; n++; }
+    for (i = 0; i < n; i++) {
+        memset(seen, 0, sizeof seen);
+        if (!mel_try(B, it, n, i, owner, seen)) abort();
+    }
+    for (i = 0; i < SEA_LANES; i++) { t->melLaneBase[i] = 0; t->melLaneFb[i] = -1; }
+    for (i = 0; i < n; i++) {
+        const band_t *b = &B[it[i].b];
+        int lane, lead = b->start - it[i].base;
+        g = it[i].slot / 32;
+        if (fill[g] >= 32 || (SEA_CC_PWROW & 1)) abort();
+        lane = 32 * g + fill[g]++;
+        t->melLaneBase[lane] = it[i].base + SEA_CC_PWROW * it[i].h;
+        t->melLaneFb[lane] = 24 * it[i].h + it[i].b;
+        for (j = 0; j < b->len; j++) t->melLaneW[lead + j][lane] = b->w[j];
+    }
+    for (g = 0; g < 2; g++) { /* no two lanes of a group on one pair of banks */
+        memset(seen, 0, sizeof seen);
+        for (i = 32 * g; i < 32 * g + fill[g]; i++) {
+            int bank = (t->melLaneBase[i] / 2) % 32;
+            if (seen[bank]) abort();
+            seen[bank] = 1;
+        }
+    }
+}
+
 void sea_build_cc_tables(sea_cc_tables *t)
 {
     band_t B[SEA_CC_NCHAN];
@@ -344,6 +401,7 @@ void sea_build_cc_tables(sea_cc_tables *t)
         for (i = 0; i < 12; i++) t->dctT[j][i] = t->dct[j][i];
         t->dctT[j][12] = 1.0f;
     }
+    cc_mel_lanes(B, t);
 }
 
 void sea_ns_plain_tables(float *sigWindow200, float *irWindow17, float *idct25x25, int *melStart25,

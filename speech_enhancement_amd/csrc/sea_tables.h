@@ -25,6 +25,8 @@ enum {
     SEA_FFT_LSTAGES = 6,   /* split-radix levels n2 = 8..256 that go through LDS */
     SEA_CC_NCHAN = 23,     /* CC_NUM_CHANNELS_WI8 etsi/cpp/CompCeps.c:37 */
     SEA_CC_TAPS = 22,      /* widest of the 23 cepstral mel triangles (asserted at build) */
+    SEA_CC_TAPS2 = 24,     /* taps per lane of the tiled kernels' mel pass (aligned pairs, see melLaneBase) */
+    SEA_CC_PWROW = 152,    /* words per power row of the tiled kernels: 129 bins, zeros behind */
     SEA_CC_NCEP = 14,      /* c1..c12, c0, logE   etsi/cpp/CompCeps.c:539-543 */
     SEA_GT_NCHAN = 64      /* NUMBER_CHANNEL      resyth_64sub_ori/cpp/HuWang.h:13 */
 };
@@ -106,6 +108,13 @@ typedef struct {
     float win8[8][SEA_LANES];                     /* Hamming(200)[(l & 31) + 32 * bitrev3(j)], 0 beyond 199 */
     float dctT[SEA_CC_NCHAN][16];                 /* [j][c]: c = 0..11 the DCT rows of c1..c12, c = 12 all ones (c0 is
                                                      the plain sum of the 23 log energies: x * 1.0f == x), 13..15 zero */
+    /* the mel pass of the tiled kernels, lane = one (frame of the pair, band): every lane reads SEA_CC_TAPS2 power bins as
+     * SEA_CC_TAPS2 / 2 aligned pairs (ds_read_b64: 64 banks, two groups of 32 lanes) from an even bin at or below its band's
+     * first one, zero weights in front and behind.  The 46 (frame, band) items are dealt to the lanes, and each picks its even
+     * first bin, by a bipartite matching such that no two lanes of a group read the same pair of banks (cc_mel_lanes). */
+    int melLaneBase[SEA_LANES];                   /* word offset from the pair's first power row (row h at SEA_CC_PWROW * h) */
+    int melLaneFb[SEA_LANES];                     /* 24 h + band: where the lane's sum goes in fb[2 pr][..]; -1: idle lane */
+    float melLaneW[SEA_CC_TAPS2][SEA_LANES];
 } sea_cc_tables;
 
 typedef struct {
