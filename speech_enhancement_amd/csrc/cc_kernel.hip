@@ -194,9 +194,6 @@ constexpr int kCcT = SEA_CC_TILE;
 #ifndef SEA_CC_FASTLOG
 #define SEA_CC_FASTLOG 1
 #endif
-#ifndef SEA_CC_LAT
-#define SEA_CC_LAT 0
-#endif
 #ifndef SEA_CC_WAVES
 #define SEA_CC_WAVES 3 /* waves per SIMD the register allocation leaves room for (LDS allows twelve waves per CU) */
 #endif
@@ -238,7 +235,9 @@ struct CcTileConst {
     Fft2Regs fft;
     float win8[8];
     int qd[8], qm[8];                 /* word offsets of Data[idx], Data[idx-1] from the frame's base; qd < 0: idx >= 200 */
-    unsigned pa[4], nyq;              /* byte offsets in a work area: Re(l), Im(l), Re(l+64), Im(l+64); x[128] */
+    int pwAB, pwCD;                   /* words from the pair's first power row: bins j (+ 64) and 64 - j (+ 64) of this lane's
+                                         last-level item (rfft256_dual_keep_last), row of its transform */
+    bool pairLane;                    /* the item with bins 0, 64, 128 | 32, 96 */
     int melBase, melFb;               /* this lane's (frame, band) of the mel pass: sea_tables.h, melLaneBase */
     float melW[SEA_CC_TAPS2];
     float floorFB, floorE;
@@ -262,11 +261,13 @@ __device__ __forceinline__ void load_cc_tile_const(CcTileConst &C, CcTileLds<SHA
         C.qd[k] = (idx < SEA_WIN) ? cc_q<SHARED>(idx + 1) : -1;
         C.qm[k] = (idx < SEA_WIN) ? cc_q<SHARED>(idx) : 0;
     }
-    C.pa[0] = fft_swz((unsigned)lane);
-    C.pa[1] = fft_swz((unsigned)(256 - lane) & 255u); /* lane 0: unused */
-    C.pa[2] = fft_swz((unsigned)lane + 64u);
-    C.pa[3] = fft_swz(192u - (unsigned)lane);
-    C.nyq = fft_swz(128u);
+    {
+        const unsigned item = t->fft.fft2Item[SEA_FFT_LSTAGES - 1][lane & 31];
+        C.pairLane = (item >> 16) == SEA_BF_PAIR;
+        const int ja = (int)(item & 255u), jc = C.pairLane ? (int)((item >> 8) & 255u) : ja; /* j, j | 0, 32 */
+        C.pwAB = SEA_CC_PWROW * (lane >> 5) + ja;
+        C.pwCD = SEA_CC_PWROW * (lane >> 5) + 64 - jc;
+    }
     C.melBase = t->melLaneBase[lane];
     C.melFb = t->melLaneFb[lane];
 #pragma unroll
@@ -342,19 +343,20 @@ __device__ __forceinline__ void cc_tile(CcTileLds<SHARED, T> &L, const CcTileCon
             }
             e[k] = v;
         }
-        rfft256_dual<false, SEA_CC_LAT != 0>(e, L.work, C.fft);
-        /* power spectrum, products and sum in double (:451-459), both frames */
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const float *w = L.work + 256 * hh;
-            const double r0 = (double)fft_at(w, C.pa[0]), r1 = (double)fft_at(w, C.pa[2]);
-            const double m0 = (lane > 0) ? (double)fft_at(w, C.pa[1]) : 0.0, m1 = (double)fft_at(w, C.pa[3]);
-            L.pw[hh][lane] = (lane > 0) ? (float)(r0 * r0 + m0 * m0) : (float)(r0 * r0);
-            L.pw[hh][lane + 64] = (float)(r1 * r1 + m1 * m1);
-            if (lane == 0) {
-                const double ny = (double)fft_at(w, C.nyq);
-                L.pw[hh][128] = (float)(ny * ny);
-            }
+        /* the transform's last level stays in registers: every lane holds four complete bins of its frame (one lane per frame
+         * five), whose power -- products and sum in double (:451-459) -- goes straight to the frame's row */
+        float o[8];
+        rfft256_dual_keep_last<false>(e, L.work, C.fft, o);
+        {
+            const bool pl = C.pairLane;
+            const float ia = pl ? 0.0f : o[7], ib = pl ? o[3] : o[6], ic = pl ? o[7] : o[3], id = pl ? o[6] : o[2];
+            auto power = [](float re, float im) { return (float)((double)re * (double)re + (double)im * (double)im); };
+            float *rowAB = &L.pw[0][0] + C.pwAB, *rowCD = &L.pw[0][0] + C.pwCD;
+            rowAB[0] = power(o[0], ia);   /* bin j | 0: (float)(re * re + 0.0) == (float)(re * re) */
+            rowAB[64] = power(o[1], ib);  /* bin 64 + j | 64 */
+            rowCD[0] = power(o[4], ic);   /* bin 64 - j | 32 */
+            rowCD[64] = power(o[5], id);  /* bin 128 - j | 96 */
+            if (pl) rowAB[128] = power(o[2], 0.0f); /* bin 128 */
         }
         wave_sync();
         /* 23 mel triangles (DoMelFB, MelProc.c:82-104): lane = one (frame, band) of the pair, dealt so that the aligned

@@ -674,6 +674,25 @@ __device__ __forceinline__ void rfft256_dual(float (&e)[8], float *work, const F
     }
 }
 
+/* The throughput form with the LAST level's results left in registers (no store): the lane's item of level n2 = 256 is, for
+ * slots 0..30 (SEA_BF_TWIDDLE, j = slot + 1), o[0..7] = x[j], x[64+j], x[128+j], x[192+j], x[64-j], x[128-j], x[192-j], x[256-j]
+ * -- four complete bins: (Re, Im) of j = (o0, o7), of 64+j = (o1, o6), of 64-j = (o4, o3), of 128-j = (o5, o2) -- and for slot 31
+ * (SEA_BF_PAIR) x[0], x[64], x[128], x[192], x[32], x[96], x[160], x[224]: bins 0 = o0, 64 = (o1, o3), 128 = o2, 32 = (o4, o7),
+ * 96 = (o5, o6) (sea_tables.c build_fft, half-wave items; rfft.c:100-174).  A caller that only needs |X|^2 saves the level's
+ * eight stores, its own reads of the spectrum and one LDS round trip. */
+template <bool ADDR_LDS>
+__device__ __forceinline__ void rfft256_dual_keep_last(float (&e)[8], float *work, const Fft2Regs &R, float (&o)[8])
+{
+    rfft256_dual_lo<ADDR_LDS>(e, work, R);
+    fft2_level<3, ADDR_LDS>(work, R);
+    wave_sync();
+    fft2_level<4, ADDR_LDS>(work, R);
+    wave_sync();
+    Fft2Ops in;
+    fft2_load<5, ADDR_LDS>(work, R, in);
+    fft2_butterfly_branchy<5>(R, in, o);
+}
+
 /* float -> int16 exactly as the reference's (short) cast behaves on x86-64: truncate toward zero
  * to int32 and keep the low 16 bits; out-of-int32-range gives 0 (etsi/cpp/ParmInterface.c:266). */
 __device__ __forceinline__ int cast_i16(float v)
