@@ -49,6 +49,10 @@ rm -rf /tmp/p_big_sq1 /tmp/p_big_mix1
 echo "profile_round: pmc SQ set 1, configs[4] form"; pass rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY \
     --output-format csv -d /tmp/p_big_sq1 -- python3 $R/bench.py $BIG > /tmp/p_big_sq1.log 2>&1
 python3 $R/tools/prof_summary.py /tmp/p_big_sq1 $O/${TAG}_pmc_big_sq1.txt --delete-raw > /dev/null
+rm -rf /tmp/p_big_sq2
+echo "profile_round: pmc SQ set 2 (LDS), configs[4] form"; pass rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_SCA \
+    --output-format csv -d /tmp/p_big_sq2 -- python3 $R/bench.py $BIG > /tmp/p_big_sq2.log 2>&1
+python3 $R/tools/prof_summary.py /tmp/p_big_sq2 $O/${TAG}_pmc_big_sq2.txt --delete-raw > /dev/null
 echo "profile_round: pmc instruction mix, configs[4] form"; pass rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 \
     --output-format csv -d /tmp/p_big_mix1 -- python3 $R/bench.py $BIG > /tmp/p_big_mix1.log 2>&1
 python3 $R/tools/prof_summary.py /tmp/p_big_mix1 $O/${TAG}_pmc_big_mix1.txt --delete-raw > /dev/null
