@@ -209,6 +209,28 @@ def test_compceps_vs_oracle(oracle):
     assert np.abs(sea.DoCompCeps(z) - oracle.compceps_frame(z)).max() <= 1e-3
 
 
+def test_compceps_frames_amplitudes_and_ragged_tiles(oracle):
+    """sea_compceps_frames (the tiled kernel: 16 frames per wave, two per transform, the mel pass's lanes dealt to
+    (frame, band) items) on arbitrary 201-float frames: every count 1..35 (partial tiles, odd pairs) and amplitudes from the
+    floors (e^-50, e^-10: CompCeps.c:405-406) up to 1e14 (power spectrum ~1e33: still finite in float).  Bit-identical to
+    the restatement frame by frame (tolerance of north_star: 1e-3 relative to the log domain; measured 0.0)."""
+    import speech_enhancement_amd as sea
+    torch = _torch()
+    rng = np.random.default_rng(77)
+    base = rng.standard_normal((35, 201)).astype(np.float32)
+    for n in (1, 2, 3, 15, 16, 17, 31, 32, 33, 35):
+        got = sea.compceps_frames(torch.from_numpy(base[:n] * np.float32(300.0)).cuda()).cpu().numpy()
+        want = np.stack([oracle.compceps_frame(base[i] * np.float32(300.0)) for i in range(n)])
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"{n} frames"
+    for sc in (1e-30, 1e-12, 1e-6, 1e-3, 1.0, 1e4, 1e9, 1e14):
+        data = base * np.float32(sc)
+        data[5] = 0.0  # a silent frame inside the tile
+        got = sea.compceps_frames(torch.from_numpy(data).cuda()).cpu().numpy()
+        want = np.stack([oracle.compceps_frame(data[i]) for i in range(len(data))])
+        assert np.isfinite(got).all(), f"scale {sc}"
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"scale {sc}: max |d| {np.abs(got - want).max()}"
+
+
 def test_ns_stream_plugin_vs_oracle(oracle):
     """DoNoiseSup-shaped streaming (state in HBM between calls) == the batch path == the oracle."""
     import speech_enhancement_amd as sea
