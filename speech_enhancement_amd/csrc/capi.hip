@@ -355,7 +355,10 @@ int sea_afe_features_batch(const float *d_den_f32, const unsigned char *d_flags,
     a.n_utt = n_utt;
     if (total_ceps > 0) {
         const long long nslot = total_ceps / 8 + n_utt; /* tile slots of 8 frames (cc_kernel.hip, kAfeT) */
-        const long long want = nslot < 8192 ? nslot : 8192;
+#ifndef SEA_AFE_GRID
+#define SEA_AFE_GRID 8192
+#endif
+        const long long want = nslot < SEA_AFE_GRID ? nslot : SEA_AFE_GRID;
         hipLaunchKernelGGL(sea::afe_ceps_kernel, dim3((unsigned)want), dim3(64), 0, (hipStream_t)stream, a);
         HIP_TRY(hipGetLastError());
     }
@@ -409,7 +412,7 @@ int sea_compceps_batch(const float *d_den_f32, const long long *d_offsets, const
     a.n_utt = n_utt;
     const long long nslot = total_frames / 16 + n_utt; /* tile slots of 16 frames (cc_kernel.hip, kCcT) */
 #ifndef SEA_CC_GRID
-#define SEA_CC_GRID 8192
+#define SEA_CC_GRID 16384 /* waves of the launch (3072 are resident): 8192 0.63 ms, 13312-24576 0.59-0.61, 3072 (every wave its share of the tiles, all in step) 1.0 */
 #endif
     const long long grid = nslot < SEA_CC_GRID ? nslot : SEA_CC_GRID;
     hipLaunchKernelGGL(sea::compceps_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)stream, a);
