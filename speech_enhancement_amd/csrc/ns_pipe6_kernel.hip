@@ -548,10 +548,23 @@ __global__ __launch_bounds__(384, SEA_NS6_BLOCKS) void ns_denoise_pipe6_kernel(N
  * per CU").  One wave slot of slack per SIMD lets all four co-reside: 2.14 ms without priorities, **2.00-2.05 ms** with the
  * issue priority by remaining frames and the wave -> role map below, against 2.08-2.13 for the four-wave form
  * (profiles/r04_ns_six_wave_dense.txt). */
+#ifdef SEA_NS6_TIMING
+__device__ unsigned g_ns6_wg[16384 * 4]; /* dense form, per workgroup: start, end (constant 100 MHz counter), HW_ID, XCC_ID (tools/ns6_residency.py) */
+#endif
 __global__ __launch_bounds__(384, 7) void ns_denoise_pipe6_dense_kernel(NsBatchArgs a)
 {
     __shared__ p6::Pipe6Lds L;
+#ifdef SEA_NS6_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {
+        g_ns6_wg[4 * blockIdx.x] = (unsigned)wall_clock64();
+        g_ns6_wg[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        g_ns6_wg[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+    }
+#endif
     p6::ns_pipe6_body<false, SEA_P6D_LOGMOVE != 0, SEA_P6D_DIFG1 != 0>(a, L);
+#ifdef SEA_NS6_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_ns6_wg[4 * blockIdx.x + 1] = (unsigned)wall_clock64();
+#endif
 }
 __global__ __launch_bounds__(384, 2) void ns_denoise_pipe6_fd_kernel(NsBatchArgs a)
 {
@@ -566,5 +579,9 @@ __global__ __launch_bounds__(384, 2) void ns_denoise_pipe6_fd_kernel(NsBatchArgs
 extern "C" int sea_debug_ns6_timing(unsigned long long *out16)
 {
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(sea::p6::g_ns6_timing), 16 * sizeof(unsigned long long));
+}
+extern "C" int sea_debug_ns6_wg(unsigned *out, int n_wg)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sea::g_ns6_wg), (size_t)n_wg * 4 * sizeof(unsigned));
 }
 #endif

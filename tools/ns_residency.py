@@ -35,3 +35,11 @@ for k in np.unique(key):
     mean.append(area / max(1, ev[-1][0] - ev[0][0]))
 print(f"{os.environ.get('SEA_NS_KERNEL', 'auto')} n_utt {n} (first {m} workgroups): CUs {len(mx)}, resident workgroups per CU: max over time min/median/max over CUs",
       int(np.min(mx)), int(np.median(mx)), int(np.max(mx)), "| time-weighted mean", round(float(np.mean(mean)), 2))
+gaps = []
+for k in np.unique(key)[:64]:
+    s, e = np.sort(start[key == k]), np.sort(end[key == k])
+    for t in e[:-6]:
+        nxt = s[s >= t]
+        if len(nxt): gaps.append(nxt[0] - t)
+if gaps: print("time from a workgroup's end to the next start on its CU (us): median", float(np.median(gaps)) * 1e-2, "p90", float(np.percentile(gaps, 90)) * 1e-2, "mean", float(np.mean(gaps)) * 1e-2)
+print("workgroup life (us): median", float(np.median(end - start)) * 1e-2)
