@@ -194,6 +194,17 @@ int sea_tables_host(float *sigWindow200, float *irWindow17, float *idct25x25, in
     return 0;
 }
 
+/* diagnostic (tests/test_host_cpu.py, no GPU): the lane map of the tiled CompCeps kernels' mel pass (sea_tables.h, melLaneBase) */
+extern "C" int sea_debug_cc_mel_lanes(int *base64, int *fb64, float *w24x64)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    host_tables();
+    memcpy(base64, g_cc_host.melLaneBase, sizeof g_cc_host.melLaneBase);
+    memcpy(fb64, g_cc_host.melLaneFb, sizeof g_cc_host.melLaneFb);
+    memcpy(w24x64, g_cc_host.melLaneW, sizeof g_cc_host.melLaneW);
+    return 0;
+}
+
 int sea_gammatone_channels(float *cf64, float *bw64, float *midEar64)
 {
     gammatone_host_tables(cf64, bw64, midEar64);

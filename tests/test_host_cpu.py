@@ -68,6 +68,42 @@ def test_host_tables_match_oracle(oracle):
     assert np.array_equal(t["cf"], cf) and np.array_equal(t["bw"], bw) and np.array_equal(t["midEar"], me)
 
 
+def test_compceps_mel_lane_map_is_complete_and_conflict_free():
+    """No GPU needed: the lane map of the tiled CompCeps kernels' mel pass (csrc/sea_tables.c: cc_mel_lanes).  Every (frame of the
+    pair, band) item sits in exactly one lane; a lane's 24 taps, read as 12 aligned pairs from an even bin, carry its band's
+    triangle weights at the band's bins and zeros elsewhere; and no two lanes of a 32-lane group start on the same pair of the
+    64 LDS banks (ds_read_b64), which holds for every tap pair since all lanes advance together."""
+    import ctypes
+    import speech_enhancement_amd as sea
+    lib = sea.load()
+    base, fb = np.zeros(64, np.int32), np.zeros(64, np.int32)
+    w = np.zeros((24, 64), np.float32)
+    assert lib.sea_debug_cc_mel_lanes(base.ctypes.data_as(ctypes.c_void_p), fb.ctypes.data_as(ctypes.c_void_p),
+                                      w.ctypes.data_as(ctypes.c_void_p)) == 0
+    t = sea.tables()
+    start, length, data = t["ccStart"], t["ccLen"], t["ccData"].reshape(23, -1)
+    row = 152  # SEA_CC_PWROW: words per power row
+    seen = set()
+    for lane in range(64):
+        if fb[lane] < 0:
+            assert not w[:, lane].any()
+            continue
+        h, band = divmod(int(fb[lane]), 24)
+        assert h in (0, 1) and 0 <= band < 23 and (h, band) not in seen
+        seen.add((h, band))
+        first = int(base[lane]) - row * h  # the lane's first bin
+        assert first % 2 == 0 and int(base[lane]) % 2 == 0 and 0 <= first <= start[band]
+        assert first + 24 >= start[band] + length[band] and first + 24 <= row
+        want = np.zeros(24, np.float32)
+        want[start[band] - first: start[band] - first + length[band]] = data[band, :length[band]]
+        assert np.array_equal(w[:, lane].view(np.uint32), want.view(np.uint32)), (lane, band)
+    assert len(seen) == 46
+    for g in (0, 1):
+        lanes = [l for l in range(32 * g, 32 * g + 32) if fb[l] >= 0]
+        banks = [(int(base[l]) // 2) % 32 for l in lanes]
+        assert len(set(banks)) == len(banks), f"group {g}: two lanes on one pair of banks"
+
+
 def test_ns16k_host_tables_and_schedule_match_oracle(oracle):
     """SURVEY 8(f) #4, no GPU needed: the product's tables of the 16 k-native variant (csrc/sea_tables.c) against the
     oracle's, bit for bit, and its table-driven transform schedule (digit-reversal places, butterflies per pass,
