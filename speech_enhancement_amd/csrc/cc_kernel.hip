@@ -483,7 +483,8 @@ __global__ __launch_bounds__(64, SEA_CC_MINW) void compceps_kernel(CepsArgs a)
              * compiler waits for each of the 22 requests in turn -- ~22 HBM latencies per tile, most of the kernel's time */
             constexpr int kReq = (SEA_HOP * (kCcT - 1) + SEA_WIN + 1 + kLanes - 1) / kLanes; /* 22 */
 #ifndef SEA_CC_STAGE_BATCH
-#define SEA_CC_STAGE_BATCH 8 /* 22 at once: 225 VGPRs, two waves per SIMD, 0.77 ms; 8: 167 VGPRs, three waves (what the LDS allows), 0.71 ms */
+#define SEA_CC_STAGE_BATCH 11 /* round 3: 22 at once two waves per SIMD 0.77 ms, 8: three waves 0.71; round 4 (three waves per SIMD forced, 168 VGPRs
+                                * either way): 8 0.610 ms, 11 = two equal batches 0.58-0.60, 12 0.60, 22 (32 spilled registers) not run */
 #endif
 #pragma unroll 1
             for (int b0 = 0; b0 < kReq; b0 += SEA_CC_STAGE_BATCH) {
