@@ -827,6 +827,49 @@ __device__ __forceinline__ void psd_from_fft2(const float *work, float *psd, con
     psd_store(o, psd, lane);
 }
 
+/* FFTtoPSD of BOTH transforms of a dual transform straight from the registers of its last level (sea_device.h,
+ * rfft256_dual_keep_last): slot s = lane & 31 of a transform holds both parts of the bins s + 1, 65 + s, 63 - s, 127 - s (slot 31: 0, 64,
+ * 32, 96 and 128), so a PSD value (P(2l) + P(2l+1)) / 2 is the sum of one kind of power of two NEIGHBOURING slots: the even slots take
+ * them -- from the slot below (cyclic within the transform's 32 lanes: wave_shr:1, slots 0 repaired from lanes 31 / 63) for the bins
+ * below 32 and from 64 to 95, from the slot above (the same quad) for the others.  Same products, same sums as psd_store; no store of
+ * the level's results, no reads of the spectrum.  (NoiseSup.c:249-270) */
+#ifndef SEA_PSD_REGS
+#define SEA_PSD_REGS 1
+#endif
+__device__ __forceinline__ void psd_from_last_level(const float (&o)[8], const Fft2Regs &R, float *psdA, bool actA, float *psdB,
+                                                    bool actB, int lane)
+{
+    const bool pl = R.kind[SEA_FFT_LSTAGES - 1] == SEA_BF_PAIR;
+    const float ia = pl ? 0.0f : o[7], ib = pl ? o[3] : o[6], ic = pl ? o[7] : o[3], id = pl ? o[6] : o[2];
+    const float Pa = o[0] * o[0] + ia * ia; /* bin s + 1 | 0: x * x + 0 * 0 == x * x */
+    const float Pb = o[1] * o[1] + ib * ib; /* bin 65 + s | 64 */
+    const float Pc = o[4] * o[4] + ic * ic; /* bin 63 - s | 32 */
+    const float Pd = o[5] * o[5] + id * id; /* bin 127 - s | 96 */
+    const float Pe = o[2] * o[2];           /* slot 31: bin 128 */
+    auto below = [&](float v) { /* the same value of slot s - 1, slot 0: of slot 31 */
+        const float sh = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
+        const float l31 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+        const float l63 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+        return lane == 0 ? l31 : (lane == 32 ? l63 : sh);
+    };
+    auto above = [&](float v) { /* of slot s + 1 (even s: the same quad) */
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xF5 /* quad_perm:[1,1,3,3] */, 0xf, 0xf, false));
+    };
+    const float qa = (below(Pa) + Pa) * 0.5f, qb = (below(Pb) + Pb) * 0.5f;
+    const float qc = (above(Pc) + Pc) * 0.5f, qd = (above(Pd) + Pd) * 0.5f;
+    const bool hi = lane >= 32;
+    float *psd = hi ? psdB : psdA;
+    const bool act = hi ? actB : actA;
+    const int t2 = (lane & 31) >> 1;
+    if (act && (lane & 1) == 0) {
+        psd[t2] = qa;
+        psd[32 + t2] = qb;
+        psd[31 - t2] = qc;
+        psd[63 - t2] = qd;
+    }
+    if (act && pl) psd[64] = Pe;
+}
+
 /* Two FRONT halves in one wave: frame A (stage buffer bufA) and frame B (bufB) are windowed,
  * transformed side by side (rfft256_dual) and reduced to their 65-bin PSDs.  actA / actB are
  * wave-uniform; an inactive side is fed zeros and its PSD is not written.  work: 512 floats. */
@@ -865,6 +908,20 @@ __device__ __forceinline__ void ns_front_dual(const float *bufA, bool actA, floa
 #ifndef SEA_BIG_LAT
 #define SEA_BIG_LAT 0 /* the table-in-LDS (large-batch, issue-bound) form keeps the throughput transform: 484 vs 468 M frames/s on the configs[4] shard */
 #endif
+    if (SEA_PSD_REGS) { /* the last level feeds the PSDs from registers */
+        float o[8];
+        if (!ADDR_LDS || SEA_BIG_LAT) { /* the latency form: levels chained */
+            rfft256_head8(e, work, fft);
+            wave_sync();
+            fft2_levels_keep_last<1, 5, ADDR_LDS>(work, fft, e, o);
+        } else {
+            rfft256_dual_lo<ADDR_LDS>(e, work, fft);
+            rfft256_dual_hi_keep_last<ADDR_LDS>(work, fft, o);
+        }
+        psd_from_last_level(o, fft, psdA, actA, psdB, actB, lane);
+        wave_sync();
+        return;
+    }
     rfft256_dual<ADDR_LDS, (!ADDR_LDS || SEA_BIG_LAT)>(e, work, fft);
     /* both PSDs' operands in one batch of reads */
     PsdOps a, b;

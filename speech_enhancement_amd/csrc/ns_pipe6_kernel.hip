@@ -303,9 +303,15 @@ __device__ __forceinline__ void ns_pipe6_body(const NsBatchArgs &a, Pipe6Lds &L)
                 const bool actB = (f1 >= 0 && f1 < nfr) && valid1 && t1 >= 5;
                 float *work = L.work[g & 1];
                 if (actA || actB) {
-                    rfft256_dual_hi<false>(work, fft);
-                    if (actA) psd_from_fft2(work, L.p0[f0 & 1].psd, fft, lane);
-                    if (actB) psd_from_fft2(work + 256, L.p1[f1 & 1].psd, fft, lane);
+                    if (SEA_PSD_REGS) { /* the last level stays in registers and feeds both PSDs (ns_core.h, psd_from_last_level) */
+                        float o[8];
+                        rfft256_dual_hi_keep_last<false>(work, fft, o);
+                        psd_from_last_level(o, fft, L.p0[f0 & 1].psd, actA, L.p1[(f1 < 0 ? 0 : f1) & 1].psd, actB, lane);
+                    } else {
+                        rfft256_dual_hi<false>(work, fft);
+                        if (actA) psd_from_fft2(work, L.p0[f0 & 1].psd, fft, lane);
+                        if (actB) psd_from_fft2(work + 256, L.p1[f1 & 1].psd, fft, lane);
+                    }
                     wave_sync();
                 }
                 if (lane == 0) {

@@ -636,6 +636,23 @@ __device__ __forceinline__ void fft2_levels(float *work, const Fft2Regs &R, floa
     if constexpr (S0 < S1) fft2_levels<S0 + 1, S1, ADDR_LDS>(work, R, o);
     else fft2_keep(o);
 }
+/* the same chain with level S1's results left in `last` instead of stored (rfft256_dual_keep_last) */
+template <int S0, int S1, bool ADDR_LDS>
+__device__ __forceinline__ void fft2_levels_keep_last(float *work, const Fft2Regs &R, float (&prev)[8], float (&last)[8])
+{
+    Fft2Ops in;
+    fft2_load<S0, ADDR_LDS>(work, R, in);
+    fft2_keep(prev);
+    if constexpr (S0 < S1) {
+        float o[8];
+        fft2_butterfly<S0>(R, in, o);
+        fft2_store<S0>(work, R, in, o);
+        wave_sync();
+        fft2_levels_keep_last<S0 + 1, S1, ADDR_LDS>(work, R, o, last);
+    } else {
+        fft2_butterfly<S0>(R, in, last);
+    }
+}
 
 template <bool ADDR_LDS>
 __device__ __forceinline__ void rfft256_dual_lo(float (&e)[8], float *work, const Fft2Regs &R)
@@ -672,6 +689,19 @@ __device__ __forceinline__ void rfft256_dual(float (&e)[8], float *work, const F
         rfft256_dual_lo<ADDR_LDS>(e, work, R);
         rfft256_dual_hi<ADDR_LDS>(work, R);
     }
+}
+
+/* second half of the dual transform with the last level's results left in registers (see rfft256_dual_keep_last) */
+template <bool ADDR_LDS>
+__device__ __forceinline__ void rfft256_dual_hi_keep_last(float *work, const Fft2Regs &R, float (&o)[8])
+{
+    fft2_level<3, ADDR_LDS>(work, R);
+    wave_sync();
+    fft2_level<4, ADDR_LDS>(work, R);
+    wave_sync();
+    Fft2Ops in;
+    fft2_load<5, ADDR_LDS>(work, R, in);
+    fft2_butterfly_branchy<5>(R, in, o);
 }
 
 /* The throughput form with the LAST level's results left in registers (no store): the lane's item of level n2 = 256 is, for
