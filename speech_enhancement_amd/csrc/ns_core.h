@@ -911,9 +911,15 @@ __device__ __forceinline__ void ns_front_dual(const float *bufA, bool actA, floa
     if (SEA_PSD_REGS) { /* the last level feeds the PSDs from registers */
         float o[8];
         if (!ADDR_LDS || SEA_BIG_LAT) { /* the latency form: levels chained */
-            rfft256_head8(e, work, fft);
-            wave_sync();
-            fft2_levels_keep_last<1, 5, ADDR_LDS>(work, fft, e, o);
+            if (SEA_FFT_HEAD16 && ADDR_LDS) {
+                rfft256_head16(e, work, fft);
+                wave_sync();
+                fft2_levels_keep_last<2, 5, ADDR_LDS>(work, fft, e, o);
+            } else {
+                rfft256_head8(e, work, fft);
+                wave_sync();
+                fft2_levels_keep_last<1, 5, ADDR_LDS>(work, fft, e, o);
+            }
         } else {
             rfft256_dual_lo<ADDR_LDS>(e, work, fft);
             rfft256_dual_hi_keep_last<ADDR_LDS>(work, fft, o);

@@ -330,6 +330,12 @@ __device__ __forceinline__ void rfft256(float e0, float e1, float e2, float e3, 
 #define SEA_FFT_PACKED 1
 #endif
 
+#ifndef SEA_FFT_HEAD16
+#define SEA_FFT_HEAD16 1 /* the n2 = 16 level of the dual transform on registers (rfft256_head16): one LDS round trip less per transform.
+                          * Only in the table-in-LDS forms (ADDR_LDS: the large-batch NoiseSup kernels, where the LDS array is the busier
+                          * pipe: configs[4] shard 477 -> 481 M frames/s); everywhere else the ~25 extra vector instructions cost what the
+                          * sixteen LDS instructions save (configs[1] 1.966 -> 1.981 ms, CompCeps unchanged) */
+#endif
 struct Fft2Regs {
     unsigned kind[SEA_FFT_LSTAGES];
     unsigned addr[SEA_FFT_LSTAGES][4]; /* byte offsets of the eight operands, two per word, already moved
@@ -339,6 +345,8 @@ struct Fft2Regs {
     unsigned headA[2], psdA[2];        /* frame A: where this lane stores its head values / finds its PSD inputs */
     unsigned nyq;
     unsigned head8Flags, head8[4];     /* the eight-positions-per-lane start (sea_tables.h fft8*), this lane's transform */
+    unsigned head16[4];                /* SEA_FFT_HEAD16: where the lane's results of the register-resident n2 = 16 level go (fft16*) */
+    float tw16[4];                     /* the one twiddle set of that level (j = 1) */
 };
 
 
@@ -367,9 +375,13 @@ __device__ __forceinline__ void load_fft2_regs(Fft2Regs &R, const sea_fft_tables
     R.psdA[0] = t->fft2Psd[0][lane];
     R.psdA[1] = t->fft2Psd[1][lane];
     R.nyq = t->fft2Nyq;
-    R.head8Flags = t->fft8Flags[lane];
+    R.head8Flags = (SEA_FFT_HEAD16 && ADDR_LDS) ? t->fft16Flags[lane] : t->fft8Flags[lane];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) R.head8[q] = t->fft8Addr[q][lane] + both;
+    for (int q = 0; q < 4; ++q) {
+        R.head8[q] = t->fft8Addr[q][lane] + both;
+        R.head16[q] = t->fft16Addr[q][lane] + both;
+        R.tw16[q] = t->fft2Tw[1][q][0]; /* level n2 = 16 has one twiddled item per block, j = 1: slot 0 is one of them */
+    }
 }
 
 /* One split-radix level of the dual transform in three pieces, so that the caller can put the NEXT level's operand
@@ -475,14 +487,12 @@ __device__ __forceinline__ void fft2_butterfly(const Fft2Regs &R, const Fft2Ops 
 /* The throughput-bound users of the transform (rfft256, CompCeps, IRM: many waves per SIMD) keep the butterfly kinds as
  * a divergent branch: both sides still issue, but without the eight selects and the extra live registers of the
  * branch-free form (CompCeps 0.87 -> 1.09 ms with the branch-free form). */
-template <int S>
-__device__ __forceinline__ void fft2_butterfly_branchy(const Fft2Regs &R, const Fft2Ops &in, float (&o)[8])
+__device__ __forceinline__ void fft2_bf_kind(const unsigned kind, const float (&tw)[4], const float (&x)[8], float (&o)[8])
 {
-    const unsigned kind = R.kind[S];
-    const float x1 = in.x[0], x2 = in.x[1], x3 = in.x[2], x4 = in.x[3], x5 = in.x[4], x6 = in.x[5], x7 = in.x[6], x8 = in.x[7];
+    const float x1 = x[0], x2 = x[1], x3 = x[2], x4 = x[3], x5 = x[4], x6 = x[5], x7 = x[6], x8 = x[7];
     float o1, o2, o3, o4, o5, o6, o7, o8;
     if (kind == SEA_BF_TWIDDLE) { /* rfft.c:145-174 */
-        const float cc1 = R.tw[S][0], ss1 = R.tw[S][1], cc3 = R.tw[S][2], ss3 = R.tw[S][3];
+        const float cc1 = tw[0], ss1 = tw[1], cc3 = tw[2], ss3 = tw[3];
         typedef float v2f __attribute__((ext_vector_type(2)));
         const v2f a37 = {x3, x7}, a48 = {x4, x8}, w1 = {cc1, ss1}, w3 = {cc3, ss3};
         v2f p1, q1, p3, q3;
@@ -511,6 +521,11 @@ __device__ __forceinline__ void fft2_butterfly_branchy(const Fft2Regs &R, const 
         o5 = x5 + u2;
     }
     o[0] = o1, o[1] = o2, o[2] = o3, o[3] = o4, o[4] = o5, o[5] = o6, o[6] = o7, o[7] = o8;
+}
+template <int S>
+__device__ __forceinline__ void fft2_butterfly_branchy(const Fft2Regs &R, const Fft2Ops &in, float (&o)[8])
+{
+    fft2_bf_kind(R.kind[S], R.tw[S], in.x, o);
 }
 
 template <int S>
@@ -577,9 +592,8 @@ __device__ __forceinline__ void rfft256_head(float e0, float e1, float e2, float
  * only) and the n2 = 8 level (:100-125, plain + pi/4 butterflies, no twiddles yet) touch nothing outside
  * such a block, so all three run on registers, gated per block by the reference's is/id schedule
  * (fft8Flags); the eight results go to their swizzled places in this lane's work area. */
-__device__ __forceinline__ void rfft256_head8(float (&e)[8], float *work, const Fft2Regs &R)
+__device__ __forceinline__ void rfft256_head8_regs(float (&e)[8], const unsigned fl)
 {
-    const unsigned fl = R.head8Flags;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const float a = e[2 * p], b = e[2 * p + 1], sum = a + b, dif = a - b;
@@ -615,6 +629,38 @@ __device__ __forceinline__ void rfft256_head8(float (&e)[8], float *work, const 
         e[5] = f ? o7 : x7;
         e[7] = f ? o8 : x8;
     }
+}
+/* SEA_FFT_HEAD16: ... and the n2 = 16 level (rfft.c:100-174 at n2 = 16; sea_tables.h fft16*).  Lane and lane ^ 16 hold the two halves
+ * of a 16-block; the lower one gives its four odd positions and takes the upper one's four even ones (v_permlane16_swap), then runs the
+ * block's PAIR item on the eight even positions while the upper one runs the twiddled item (j = 1) on the eight odd ones -- the
+ * butterflies of fft2_bf_kind on registers.  A block outside the level's schedule passes through.  One LDS round trip (eight stores,
+ * eight loads per lane) less than head8 + fft2_level<1>. */
+__device__ __forceinline__ void rfft256_head16(float (&e)[8], float *work, const Fft2Regs &R)
+{
+    rfft256_head8_regs(e, R.head8Flags);
+    const bool up = (threadIdx.x & 16u) != 0; /* the half at positions 16b + 8 .. 16b + 15 */
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float give = up ? e[2 * i] : e[2 * i + 1];
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(give), __float_as_uint(give), false, false);
+        r[i] = __uint_as_float(up ? sw[0] : sw[1]); /* odd rows find the even row's value in [0], even rows the odd row's in [1] */
+    }
+    /* item order: a, a + n4, a + 2 n4, a + 3 n4, b, ...: lower half (PAIR) 0 4 8 12 | 2 6 10 14, upper half (j = 1) 1 5 9 13 | 3 7 11 15 */
+    const float x[8] = {up ? r[0] : e[0], up ? r[2] : e[4], up ? e[1] : r[0], up ? e[5] : r[2],
+                        up ? r[1] : e[2], up ? r[3] : e[6], up ? e[3] : r[1], up ? e[7] : r[3]};
+    float o[8];
+    fft2_bf_kind(up ? (unsigned)SEA_BF_TWIDDLE : (unsigned)SEA_BF_PAIR, R.tw16, x, o);
+    const bool on = (R.head8Flags & 128u) != 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        fft_at(work, R.head16[q] & 0xffffu) = on ? o[2 * q] : x[2 * q];
+        fft_at(work, R.head16[q] >> 16) = on ? o[2 * q + 1] : x[2 * q + 1];
+    }
+}
+__device__ __forceinline__ void rfft256_head8(float (&e)[8], float *work, const Fft2Regs &R)
+{
+    rfft256_head8_regs(e, R.head8Flags);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         fft_at(work, R.head8[q] & 0xffffu) = e[2 * q];
@@ -657,10 +703,15 @@ __device__ __forceinline__ void fft2_levels_keep_last(float *work, const Fft2Reg
 template <bool ADDR_LDS>
 __device__ __forceinline__ void rfft256_dual_lo(float (&e)[8], float *work, const Fft2Regs &R)
 {
-    rfft256_head8(e, work, R);
-    wave_sync();
-    fft2_level<1, ADDR_LDS>(work, R);
-    wave_sync();
+    if (SEA_FFT_HEAD16 && ADDR_LDS) {
+        rfft256_head16(e, work, R);
+        wave_sync();
+    } else {
+        rfft256_head8(e, work, R);
+        wave_sync();
+        fft2_level<1, ADDR_LDS>(work, R);
+        wave_sync();
+    }
     fft2_level<2, ADDR_LDS>(work, R);
     wave_sync();
 }
@@ -682,9 +733,15 @@ template <bool ADDR_LDS, bool LAT = false>
 __device__ __forceinline__ void rfft256_dual(float (&e)[8], float *work, const Fft2Regs &R)
 {
     if (LAT) {
-        rfft256_head8(e, work, R);
-        wave_sync();
-        fft2_levels<1, 5, ADDR_LDS>(work, R, e);
+        if (SEA_FFT_HEAD16 && ADDR_LDS) {
+            rfft256_head16(e, work, R);
+            wave_sync();
+            fft2_levels<2, 5, ADDR_LDS>(work, R, e);
+        } else {
+            rfft256_head8(e, work, R);
+            wave_sync();
+            fft2_levels<1, 5, ADDR_LDS>(work, R, e);
+        }
     } else {
         rfft256_dual_lo<ADDR_LDS>(e, work, R);
         rfft256_dual_hi<ADDR_LDS>(work, R);

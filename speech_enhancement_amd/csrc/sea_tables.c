@@ -166,6 +166,20 @@ static void build_fft(sea_fft_tables *f)
             f->fft8Flags[lane] = fl;
         }
     }
+    {   /* the n2 = 16 level on registers: see sea_tables.h, fft16* */
+        static const unsigned evenPos[8] = {0, 4, 8, 12, 2, 6, 10, 14}, oddPos[8] = {1, 5, 9, 13, 3, 7, 11, 15};
+        mark_ctx len16;
+        memset(&len16, 0, sizeof len16);
+        for_each_block(SEA_NFFT, 16, 0, mark_visit, &len16);
+        for (lane = 0; lane < SEA_LANES; lane++) {
+            unsigned k = bitrev((unsigned)lane & 31u, 5), blk = 16u * (k >> 1), q;
+            const unsigned *pos = (k & 1u) ? oddPos : evenPos;
+            if ((k & 1u) != (((unsigned)lane >> 4) & 1u)) abort(); /* the second half of a 16-block sits 16 lanes up */
+            f->fft16Flags[lane] = f->fft8Flags[lane] | (len16.mark[blk] ? 128u : 0u);
+            for (q = 0; q < 4; q++)
+                f->fft16Addr[q][lane] = (sea_fft_swizzle(blk + pos[2 * q]) * 4u) | ((sea_fft_swizzle(blk + pos[2 * q + 1]) * 4u) << 16);
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -73,6 +73,14 @@ typedef struct {
      *   fft8Addr[q][l]  swizzled byte offsets of positions 8k+2q, 8k+2q+1 (low | high << 16) */
     unsigned fft8Flags[SEA_LANES];
     unsigned fft8Addr[4][SEA_LANES];
+    /* ... and the n2 = 16 level on registers too (round 4): the 16-block 16b..16b+15 is held by the lanes of 8-blocks k = 2b (n0 < 16)
+     * and k = 2b + 1 (n0 >= 16 = the lane 16 further: v_permlane16_swap); the first takes the block's PAIR item (even positions:
+     * plain butterfly on 16b + {0,4,8,12}, pi/4 on 16b + {2,6,10,14}), the second its one twiddled item (j = 1: 16b + {1,5,9,13},
+     * 16b + {3,7,11,15}), each after receiving the other's four values of that parity.
+     *   fft16Flags[l]   fft8Flags | bit 7: the block is in the n2 = 16 schedule
+     *   fft16Addr[q][l] swizzled byte offsets of the lane's results 2q, 2q+1 in item order (the positions listed above) */
+    unsigned fft16Flags[SEA_LANES];
+    unsigned fft16Addr[4][SEA_LANES];
 } sea_fft_tables;
 
 /* word index of element i (0..255) in the swizzled work area */
