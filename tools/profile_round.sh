@@ -65,4 +65,4 @@ python3 $R/tools/make_pmc_traffic.py $O/${TAG}_pmc_fetch.txt $O/${TAG}_pmc_write
     --big $O/${TAG}_pmc_big_fetch.txt $O/${TAG}_pmc_big_write.txt $O/${TAG}_pmc_big_sq1.txt $O/${TAG}_pmc_big_mix1.txt && cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
 cd $R
 python bench.py --no-cpu-baseline > $O/${TAG}_bench_n1_with_traffic.json 2> /dev/null   # same tree, traffic from the fresh stamp
-echo profile_round done
+echo "profile_round done -- back home copy gpurun_out/${TAG}_* AND gpurun_out/pmc_traffic.json into profiles/ (the stamp bench.py checks)"
